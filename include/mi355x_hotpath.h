@@ -1,0 +1,267 @@
+/*
+ * mi355x_hotpath.h — C-ABI of the MI355X (gfx950) quantized-inference hot path.
+ *
+ * This is the drop-in boundary: every entry point takes plain device pointers,
+ * sizes, strides (in ELEMENTS unless the name says bytes) and a HIP stream, and
+ * corresponds to one launcher of the reference extension (vLLM-metax `_C.so`).
+ * The citation after each declaration names the reference launcher whose
+ * pointer/stride extraction fixes the parameter list (paths relative to
+ * /root/reference).
+ *
+ * Conventions
+ *   - return 0 on success, a negative MI355X_E* code otherwise;
+ *     mi355x_last_error() returns a thread-local description of the last error.
+ *   - no allocation, no host sync, no global state; every launch goes to `stream`
+ *     (hipStream_t passed as void*), so every call is hipGraph-capturable unless
+ *     the comment says otherwise.
+ *   - dtype is passed as mi355x_dtype (no templates cross the ABI).
+ *   - "Tensor!" arguments of the reference schema are the non-const pointers.
+ */
+#ifndef MI355X_HOTPATH_H_
+#define MI355X_HOTPATH_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355X_ABI_VERSION 1
+
+typedef enum {
+  MI355X_F16 = 0,  /* IEEE half  (torch.float16)  */
+  MI355X_BF16 = 1, /* bfloat16   (torch.bfloat16) */
+  MI355X_F32 = 2   /* float      (torch.float32)  */
+} mi355x_dtype;
+
+enum {
+  MI355X_OK = 0,
+  MI355X_EINVAL = -1,      /* bad argument (null pointer, negative size, misalignment) */
+  MI355X_EUNSUPPORTED = -2,/* shape / dtype / feature outside the supported set        */
+  MI355X_ELAUNCH = -3      /* hipLaunch / hipMemcpyAsync reported an error             */
+};
+
+typedef void* mi355x_stream; /* hipStream_t */
+
+int mi355x_abi_version(void);
+const char* mi355x_last_error(void);
+
+/* ------------------------------------------------------------------ utils --
+ * ref: csrc/cuda_utils_kernels.cu (get_device_attribute,
+ *      get_max_shared_memory_per_block_device_attribute), schema
+ *      csrc/torch_bindings.cpp:461-468. Returns the value, or a negative code. */
+int64_t mi355x_get_device_attribute(int64_t attribute, int64_t device_id);
+int64_t mi355x_get_max_shared_memory_per_block_device_attribute(int64_t device_id);
+
+/* ------------------------------------------------------------- KV cache ops --
+ * reshape_and_cache: scatter T new K/V rows into the paged "x-split" layout
+ *   key_cache   [num_blocks, num_heads, head_size/x, block_size, x]
+ *   value_cache [num_blocks, num_heads, head_size, block_size]
+ * slot < 0 => token skipped. Pure copy (bit-exact).
+ * ref: csrc/cache_kernels.cu:407-433 (launcher), :203-255 (kernel). */
+int mi355x_reshape_and_cache(const void* key, const void* value, void* key_cache,
+                             void* value_cache, const int64_t* slot_mapping,
+                             int num_tokens, int64_t key_stride, int64_t value_stride,
+                             int num_heads, int head_size, int block_size, int x,
+                             int dtype, mi355x_stream stream);
+
+/* reshape_and_cache_flash: same into NHD [num_blocks, block_size, heads, head_size]
+ * (or HND through the strides). num_tokens = slot_mapping.size(0).
+ * ref: csrc/cache_kernels.cu:450-488 (launcher), :271-344 (kernel). */
+int mi355x_reshape_and_cache_flash(const void* key, const void* value, void* key_cache,
+                                   void* value_cache, const int64_t* slot_mapping,
+                                   int num_tokens, int64_t block_stride,
+                                   int64_t page_stride, int64_t head_stride,
+                                   int64_t key_stride, int64_t value_stride,
+                                   int num_heads, int head_size, int block_size,
+                                   int dtype, mi355x_stream stream);
+
+/* copy_blocks: for every layer l and pair p copy block src->dst inside
+ * key_caches[l] and value_caches[l]. `key_cache_ptrs`/`value_cache_ptrs` are HOST
+ * arrays of device pointers (passed to the kernel by value, so unlike the
+ * reference there is no H2D upload and no sync); `block_mapping` is a DEVICE
+ * int64 [num_pairs, 2]. bytes_per_block = numel_per_block * element_size.
+ * ref: csrc/cache_kernels.cu:116-163 (launcher), :65-91 (kernel). */
+int mi355x_copy_blocks(void* const* key_cache_ptrs, void* const* value_cache_ptrs,
+                       int num_layers, const int64_t* block_mapping, int num_pairs,
+                       int64_t bytes_per_block, mi355x_stream stream);
+
+/* swap_blocks: block copies between two caches; `block_mapping` is a HOST int64
+ * [num_pairs, 2]; kind: 0 = D2D, 1 = D2H, 2 = H2D. Runs of consecutive pairs are
+ * merged into one hipMemcpyAsync. Not graph-capturable when host memory is pageable.
+ * ref: csrc/cache_kernels.cu:18-60. */
+int mi355x_swap_blocks(const void* src, void* dst, const int64_t* block_mapping,
+                       int num_pairs, int64_t block_size_in_bytes, int kind,
+                       mi355x_stream stream);
+
+/* --------------------------------------------------------- paged attention --
+ * Single-query (decode) attention over the x-split paged KV cache.
+ *   out/query [num_seqs, num_heads, head_size] (query row stride = q_stride)
+ *   block_tables int32 [num_seqs, max_num_blocks_per_seq]; seq_lens int32 [num_seqs]
+ *   alibi_slopes float [num_heads] or NULL. kv cache dtype is always "auto"
+ *   (== query dtype), as in the reference (quant_utils.cuh:29-42).
+ * One workgroup serves ALL query heads of one KV head (GQA reuse), unlike the
+ * reference's one block per query head.
+ * ref: csrc/attention/paged_attention_v1.cu:43-125,160-182;
+ *      csrc/attention/attention_kernels.cuh:75-485. */
+int mi355x_paged_attention_v1(void* out, const void* query, const void* key_cache,
+                              const void* value_cache, int num_seqs, int num_heads,
+                              int num_kv_heads, int head_size, int block_size,
+                              float scale, const int* block_tables,
+                              const int* seq_lens, int max_num_blocks_per_seq,
+                              int max_seq_len, const float* alibi_slopes,
+                              int64_t q_stride, int64_t kv_block_stride,
+                              int64_t kv_head_stride, int dtype, mi355x_stream stream);
+
+/* Split-KV variant: partitions of MI355X_PA_PARTITION_SIZE tokens, then an
+ * LSE-rescaled reduce.  exp_sums/max_logits float [num_seqs, num_heads, P],
+ * tmp_out [num_seqs, num_heads, P, head_size], P = ceil(max_seq_len / 512).
+ * ref: csrc/attention/paged_attention_v2.cu:43-131,167-192;
+ *      csrc/attention/attention_kernels.cuh:519-658. */
+#define MI355X_PA_PARTITION_SIZE 512
+int mi355x_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
+                              void* tmp_out, const void* query, const void* key_cache,
+                              const void* value_cache, int num_seqs, int num_heads,
+                              int num_kv_heads, int head_size, int block_size,
+                              float scale, const int* block_tables,
+                              const int* seq_lens, int max_num_blocks_per_seq,
+                              int max_seq_len, const float* alibi_slopes,
+                              int64_t q_stride, int64_t kv_block_stride,
+                              int64_t kv_head_stride, int dtype, mi355x_stream stream);
+
+/* Paged prefill / chunked prefill (varlen, causal bottom-right aligned, GQA) over
+ * the SAME x-split paged cache (the new tokens were already written by
+ * reshape_and_cache).  q/out [total_q, num_heads, head_size] packed by
+ * cu_seqlens_q int32 [num_seqs+1]; seq_lens int32 [num_seqs] = context + new.
+ * ref (call site, third-party kernel): vllm_metax/v1/attention/backends/
+ *      flash_attn.py:725-747; semantic oracle tests/kernels/attention/
+ *      test_flash_attn.py:27-80. */
+int mi355x_paged_prefill_attention(void* out, const void* query, const void* key_cache,
+                                   const void* value_cache, int num_seqs, int num_heads,
+                                   int num_kv_heads, int head_size, int block_size,
+                                   float scale, const int* block_tables,
+                                   const int* seq_lens, const int* cu_seqlens_q,
+                                   int max_query_len, int max_num_blocks_per_seq,
+                                   int64_t q_stride, int64_t out_stride,
+                                   int64_t kv_block_stride, int64_t kv_head_stride,
+                                   int dtype, mi355x_stream stream);
+
+/* ------------------------------------------------------------- layernorm --
+ * ref: csrc/layernorm_kernels.cu:141-162 (rms_norm), :174-217 (fused_add). */
+int mi355x_rms_norm(void* out, const void* input, const void* weight, float epsilon,
+                    int num_tokens, int hidden_size, int64_t input_stride, int dtype,
+                    mi355x_stream stream);
+int mi355x_fused_add_rms_norm(void* input, void* residual, const void* weight,
+                              float epsilon, int num_tokens, int hidden_size,
+                              int64_t input_stride, int dtype, mi355x_stream stream);
+
+/* ref: csrc/layernorm_quant_kernels.cu:168-194, :210-249. out is float8_e4m3fn. */
+int mi355x_rms_norm_static_fp8_quant(void* out, const void* input, const void* weight,
+                                     const float* scale, float epsilon, int num_tokens,
+                                     int hidden_size, int64_t input_stride, int dtype,
+                                     mi355x_stream stream);
+int mi355x_fused_add_rms_norm_static_fp8_quant(void* out, void* input, void* residual,
+                                               const void* weight, const float* scale,
+                                               float epsilon, int num_tokens,
+                                               int hidden_size, int64_t input_stride,
+                                               int dtype, mi355x_stream stream);
+/* ref: csrc/quantization/fused_kernels/fused_layernorm_dynamic_per_token_quant.cu
+ *      :132-155; helpers layernorm_utils.cuh:17-115. residual/scale_ub may be NULL. */
+int mi355x_rms_norm_dynamic_per_token_quant(void* out, const void* input,
+                                            const void* weight, float* scales,
+                                            float epsilon, const float* scale_ub,
+                                            void* residual, int num_tokens,
+                                            int hidden_size, int dtype,
+                                            mi355x_stream stream);
+
+/* ---------------------------------------------------------------- fp8 quant --
+ * ref: csrc/quantization/fp8/common.cu:137-168, :170-212, :214-248. Strides in
+ * elements. dynamic_scaled: `scale` must be zero-initialised by the caller (the
+ * kernel folds absmax/448 in with an atomic max, as the reference does). */
+int mi355x_static_scaled_fp8_quant(void* out, const void* input, const float* scale,
+                                   int num_tokens, int hidden_size,
+                                   int64_t in_row_stride, int64_t out_row_stride,
+                                   int dtype, mi355x_stream stream);
+int mi355x_dynamic_scaled_fp8_quant(void* out, const void* input, float* scale,
+                                    int num_tokens, int hidden_size,
+                                    int64_t in_row_stride, int64_t out_row_stride,
+                                    int dtype, mi355x_stream stream);
+int mi355x_dynamic_per_token_scaled_fp8_quant(void* out, const void* input,
+                                              float* scales, const float* scale_ub,
+                                              int num_tokens, int hidden_size,
+                                              int64_t in_row_stride,
+                                              int64_t out_row_stride, int dtype,
+                                              mi355x_stream stream);
+
+/* ------------------------------------------------------------------ rotary --
+ * In-place RoPE on query and (optional) key. positions int64 [num_tokens].
+ * ref: csrc/pos_encoding_kernels.cu:133-213 (launcher), :10-100 (math). */
+int mi355x_rotary_embedding(const int64_t* positions, void* query, void* key,
+                            const void* cos_sin_cache, int num_tokens, int rot_dim,
+                            int64_t query_stride, int64_t key_stride,
+                            int64_t head_stride, int num_heads, int num_kv_heads,
+                            int head_size, int is_neox, int dtype,
+                            mi355x_stream stream);
+
+/* -------------------------------------------------------------- activation --
+ * out[t, :d] = silu(in[t, :d]) * in[t, d:2d].
+ * ref: csrc/activation_kernels.cu:24-36,142-147,243-247. */
+int mi355x_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dtype,
+                        mi355x_stream stream);
+
+/* ------------------------------------------------------- int4 weight-only --
+ * awq_to_gptq_4bit: AWQ qweight [K, N/8] (N-interleaved nibbles) -> exllama
+ * layout, memory [K/8, N] words, nibble p of word (kk,n) = W[8kk + {0,2,4,6,1,3,5,7}[p], n].
+ * ref: csrc/quantization/awq/gemm_kernels.cu:127-184 (kernel), :323-356. */
+int mi355x_awq_to_gptq_4bit(uint32_t* out, const uint32_t* qweight, int k, int n,
+                            mi355x_stream stream);
+
+/* awq_dequantize: original AWQ layout -> dense [K, N] of `dtype`.
+ * ref: csrc/quantization/awq/gemm_kernels.cu:358-402 (launcher), :96-125. */
+int mi355x_awq_dequantize(void* out, const uint32_t* qweight, const void* scales,
+                          const uint32_t* qzeros, int k, int n, int group_size,
+                          int dtype, mi355x_stream stream);
+
+/* awq_gemm: C[M,N] = A[M,K] . ((Q - Z) * S); Q in the exllama layout produced by
+ * awq_to_gptq_4bit, qzeros [K/g, N/8] in AWQ nibble order, scales [K/g, N].
+ * `workspace` (float, >= m*n when the kernel chooses split-K, may be NULL
+ * otherwise) is the reference's temp_space; it is zero-filled by the call.
+ * ref: csrc/quantization/awq/gemm_kernels.cu:410-463, :283-318, :186-281. */
+int mi355x_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* scales,
+                    const uint32_t* qzeros, float* workspace, int64_t workspace_elems,
+                    int m, int n, int k, int group_size, int64_t lda, int dtype,
+                    mi355x_stream stream);
+
+/* gptq_shuffle: in-place exllama nibble shuffle of q_weight [K/8, N]; with q_perm
+ * (int32 [K]) rows are first made sequential through `scratch` (>= K/8*N words).
+ * ref: csrc/quantization/gptq/q_gemm.cu:2415-2423, :2321-2368, qdq_4.cuh:16-29,
+ *      q_gemm.cu:2145-2174. bit must be 4 or 8. */
+int mi355x_gptq_shuffle(uint32_t* q_weight, const int* q_perm, uint32_t* scratch, int k,
+                        int n, int bit, mi355x_stream stream);
+
+/* gptq_gemm: C = A[:, perm] . ((Q - (Z + 1)) * S), 4-bit, shuffled layout.
+ * g_idx == NULL => no act-order; else g_idx is the argsort permutation and
+ * perm_space (>= m*k elements of 2 bytes) receives the permuted activations.
+ * ref: csrc/quantization/gptq/q_gemm.cu:2373-2413, :1983-2007, :1770-1786. */
+int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,
+                     const uint32_t* qzeros, const void* scales, const int* g_idx,
+                     void* perm_space, float* workspace, int64_t workspace_elems, int m,
+                     int n, int k, int bit, int group_size, int dtype,
+                     mi355x_stream stream);
+
+/* ----------------------------------------------------------------- fp8 GEMM --
+ * out[M,N] (bf16/f16) = (a_scales . a[M,K] e4m3fn row-major) x
+ *                       (b_scales . b[K,N] e4m3fn COLUMN-major, ldb = b.stride(1))
+ *                       (+ bias[N]).  a_scales: 1 or M floats; b_scales: 1 or N.
+ * New capability behind the reference schema cutlass_scaled_mm
+ * (csrc/torch_bindings.cpp:251-256; csrc/quantization/cutlass_w8a8/
+ *  scaled_mm_entry.cu:34-39,84-140), which the reference only implements for int8. */
+int mi355x_scaled_mm_fp8(void* out, const void* a, const void* b, const float* a_scales,
+                         int a_scales_numel, const float* b_scales, int b_scales_numel,
+                         const void* bias, int m, int n, int k, int64_t lda, int64_t ldb,
+                         int64_t ldc, int out_dtype, mi355x_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_HOTPATH_H_ */

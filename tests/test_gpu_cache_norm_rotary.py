@@ -1,0 +1,341 @@
+"""GPU parity: cache ops, layernorm family, fp8 quant, rotary, silu_and_mul.
+
+HIP path (through the C-ABI, vllm_metax_amd._custom_ops) vs the CPU oracle
+(oracle/ref_ops.py) on the same seeded inputs.  Parameter grids follow the reference's
+tests: tests/kernels/attention/test_cache.py:13-40, tests/kernels/core/test_layernorm.py
+:12-17, test_fused_quant_layernorm.py:13-24, test_pos_encoding.py:14-25.
+
+Tolerances (stated per SURVEY §8 / north_star):
+  * cache / copy ops: bit-exact.
+  * 16-bit normalised outputs: the only freedom is the fp32 summation order of the
+    variance, which can flip a final rounding: <= 1 ulp, on <= 0.5 % of the elements.
+  * fp8 outputs: <= 1 fp8 ulp on <= 0.5 % of elements; per-token scales rel 1e-6.
+  * rotary / silu: bit-exact for 16-bit types (pure per-element arithmetic with the
+    same rounding points); fp32 within 1e-6 relative (fma contraction).
+"""
+import pytest
+import torch
+
+from tests.util import (assert_bit_exact, assert_close_rel, assert_mostly_exact, dev)
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_ops as R  # noqa: E402
+
+
+def ops():
+    from vllm_metax_amd import _custom_ops
+    return _custom_ops
+
+
+DTYPES = [torch.float16, torch.bfloat16, torch.float32]
+
+
+# ------------------------------------------------------------------------------ cache
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("head_size", [64, 80, 128, 256])
+@pytest.mark.parametrize("block_size", [8, 16, 32])
+def test_reshape_and_cache(dtype, head_size, block_size):
+    torch.manual_seed(0)
+    T, H, nb = 42, 8, 64
+    x = 16 // torch.tensor([], dtype=dtype).element_size()
+    slots = torch.randperm(nb * block_size)[:T].to(torch.int64)
+    slots[5] = -1  # padding token must be skipped
+    qkv = torch.randn(T, 3, H, head_size).to(dtype)
+    key, value = qkv[:, 1], qkv[:, 2]  # strided rows like a split qkv
+    kc = torch.randn(nb, H, head_size // x, block_size, x).to(dtype)
+    vc = torch.randn(nb, H, head_size, block_size).to(dtype)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    R.reshape_and_cache(key, value, kc_ref, vc_ref, slots)
+    d = dev()
+    qkv_d = qkv.to(d)
+    kc_d, vc_d = kc.to(d), vc.to(d)
+    ops().reshape_and_cache(qkv_d[:, 1], qkv_d[:, 2], kc_d, vc_d, slots.to(d), "auto")
+    torch.cuda.synchronize()
+    assert_bit_exact(kc_d, kc_ref, "key_cache")
+    assert_bit_exact(vc_d, vc_ref, "value_cache")
+
+
+def test_reshape_and_cache_consecutive_prefill_slots():
+    """prefill-shaped case: 300 tokens with consecutive slots (the tiled path's fast case)."""
+    torch.manual_seed(1)
+    dtype, T, H, D, bs, nb = torch.bfloat16, 300, 8, 128, 16, 40
+    slots = (torch.arange(T) + 37).to(torch.int64)
+    key, value = torch.randn(T, H, D).to(dtype), torch.randn(T, H, D).to(dtype)
+    kc = torch.zeros(nb, H, D // 8, bs, 8, dtype=dtype)
+    vc = torch.zeros(nb, H, D, bs, dtype=dtype)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    R.reshape_and_cache(key, value, kc_ref, vc_ref, slots)
+    d = dev()
+    kc_d, vc_d = kc.to(d), vc.to(d)
+    ops().reshape_and_cache(key.to(d), value.to(d), kc_d, vc_d, slots.to(d), "auto")
+    assert_bit_exact(kc_d, kc_ref, "key_cache")
+    assert_bit_exact(vc_d, vc_ref, "value_cache")
+
+
+def test_reshape_and_cache_empty_and_bad_dtype():
+    d = dev()
+    key = torch.zeros(0, 8, 128, dtype=torch.bfloat16, device=d)
+    kc = torch.zeros(4, 8, 16, 16, 8, dtype=torch.bfloat16, device=d)
+    vc = torch.zeros(4, 8, 128, 16, dtype=torch.bfloat16, device=d)
+    ops().reshape_and_cache(key, key, kc, vc, torch.zeros(0, dtype=torch.int64, device=d), "auto")
+    with pytest.raises(RuntimeError):
+        ops().reshape_and_cache(key, key, kc, vc, torch.zeros(0, dtype=torch.int64, device=d), "fp8")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("head_size", [64, 80, 128])
+@pytest.mark.parametrize("layout", ["NHD", "HND"])
+def test_reshape_and_cache_flash(dtype, head_size, layout):
+    torch.manual_seed(0)
+    T, H, nb, bs = 42, 8, 32, 16
+    slots = torch.randperm(nb * bs)[:T].to(torch.int64)
+    slots[0] = -1
+    key = torch.randn(T + 6, H, head_size).to(dtype)  # longer than slot_mapping (graph padding)
+    value = torch.randn(T + 6, H, head_size).to(dtype)
+    if layout == "NHD":
+        cache = torch.randn(2, nb, bs, H, head_size).to(dtype)
+        view = lambda c: c
+    else:
+        cache = torch.randn(2, nb, H, bs, head_size).to(dtype)
+        view = lambda c: c.permute(0, 1, 3, 2, 4)
+    ref = cache.clone()
+    R.reshape_and_cache_flash(key, value, view(ref)[0], view(ref)[1], slots)
+    d = dev()
+    cd = cache.to(d)
+    ops().reshape_and_cache_flash(key.to(d), value.to(d), view(cd)[0], view(cd)[1], slots.to(d), "auto")
+    assert_bit_exact(cd, ref, "flash cache")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_copy_blocks(dtype):
+    torch.manual_seed(0)
+    L, nb, H, D, bs = 5, 32, 4, 64, 16
+    x = 16 // torch.tensor([], dtype=dtype).element_size()
+    kcs = [torch.randn(nb, H, D // x, bs, x).to(dtype) for _ in range(L)]
+    vcs = [torch.randn(nb, H, D, bs).to(dtype) for _ in range(L)]
+    src = torch.randperm(nb)[:6]
+    rest = [b for b in range(nb) if b not in src.tolist()]
+    mapping = []
+    for i, s in enumerate(src.tolist()):
+        mapping.append((s, rest[2 * i]))
+        mapping.append((s, rest[2 * i + 1]))
+    bm = torch.tensor(mapping, dtype=torch.int64)
+    kr, vr = [k.clone() for k in kcs], [v.clone() for v in vcs]
+    R.copy_blocks(kr, vr, bm)
+    d = dev()
+    kd, vd = [k.to(d) for k in kcs], [v.to(d) for v in vcs]
+    ops().copy_blocks(kd, vd, bm.to(d))
+    for a, b in zip(kd + vd, kr + vr):
+        assert_bit_exact(a, b, "copy_blocks")
+
+
+@pytest.mark.parametrize("direction", ["d2d", "d2h", "h2d"])
+def test_swap_blocks(direction):
+    torch.manual_seed(0)
+    nb = 24
+    src = torch.randn(nb, 4, 8, 16, 8).to(torch.bfloat16)
+    dst = torch.randn(nb, 4, 8, 16, 8).to(torch.bfloat16)
+    bm = torch.tensor([(1, 5), (2, 6), (3, 7), (10, 0), (20, 21)], dtype=torch.int64)
+    ref = dst.clone()
+    R.swap_blocks(src, ref, bm)
+    d = dev()
+    s = src.to(d) if direction in ("d2d", "d2h") else src.pin_memory()
+    t = dst.to(d) if direction in ("d2d", "h2d") else dst.pin_memory()
+    ops().swap_blocks(s, t, bm)
+    torch.cuda.synchronize()
+    assert_bit_exact(t, ref, "swap_blocks")
+    with pytest.raises(RuntimeError):
+        ops().swap_blocks(s, t, bm.to(d))  # block_mapping must be on CPU
+
+
+# -------------------------------------------------------------------------- layernorm
+NORM_TOKENS = [7, 83, 512]
+NORM_HIDDEN = [8, 768, 769, 4096, 5120, 8192, 8199]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hidden", NORM_HIDDEN)
+@pytest.mark.parametrize("tokens", NORM_TOKENS)
+@pytest.mark.parametrize("add_residual,strided", [(False, False), (True, False), (True, True), (False, True)])
+def test_rms_norm(dtype, hidden, tokens, add_residual, strided):
+    torch.manual_seed(0)
+    eps = 1e-6
+    w = (torch.randn(hidden) * 0.1 + 1.0).to(dtype)
+    last = hidden * 2 if strided else hidden
+    xfull = (torch.randn(tokens, last) * (1.0 / (2 * hidden))).to(dtype)
+    x = xfull[..., :hidden]
+    res = torch.randn(tokens, hidden).to(dtype) * 0 + (torch.randn(tokens, hidden) * (1.0 / (2 * hidden))).to(dtype)
+    d = dev()
+    xd = xfull.to(d)[..., :hidden]
+    frac, ulp = (5e-3, 1) if dtype != torch.float32 else (1.0, 64)
+    if add_residual:
+        ref_out, ref_res = R.fused_add_rms_norm(x, res, w, eps)
+        rd = res.to(d)
+        ops().fused_add_rms_norm(xd, rd, w.to(d), eps)
+        assert_bit_exact(rd, ref_res, "residual") if dtype != torch.float32 else assert_close_rel(rd, ref_res, 1e-6)
+        assert_mostly_exact(xd.contiguous(), ref_out, ulp, frac, "fused_add_rms_norm out")
+    else:
+        ref_out = R.rms_norm(x, w, eps)
+        out = torch.empty(tokens, hidden, dtype=dtype, device=d)
+        ops().rms_norm(out, xd, w.to(d), eps)
+        assert_mostly_exact(out, ref_out, ulp, frac, "rms_norm out")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("hidden", [64, 769, 4096, 8192])
+@pytest.mark.parametrize("tokens", [1, 7, 83])
+@pytest.mark.parametrize("add_residual", [False, True])
+def test_rms_norm_static_fp8_quant(dtype, hidden, tokens, add_residual):
+    torch.manual_seed(0)
+    eps = 1e-6
+    w = (torch.randn(hidden) * 0.1 + 1.0).to(dtype)
+    x = torch.randn(tokens, hidden).to(dtype)
+    res = torch.randn(tokens, hidden).to(dtype)
+    scale = torch.tensor([0.02], dtype=torch.float32)
+    d = dev()
+    out = torch.empty(tokens, hidden, dtype=torch.float8_e4m3fn, device=d)
+    if add_residual:
+        ref_q, ref_res = R.fused_add_rms_norm_static_fp8_quant(x, res, w, scale, eps)
+        xd, rd = x.to(d), res.to(d)
+        ops().fused_add_rms_norm_static_fp8_quant(out, xd, rd, w.to(d), scale.to(d), eps)
+        assert_bit_exact(rd, ref_res, "residual")
+        assert_bit_exact(xd, x, "input must stay untouched")
+    else:
+        ref_q = R.rms_norm_static_fp8_quant(x, w, scale, eps)
+        ops().rms_norm_static_fp8_quant(out, x.to(d), w.to(d), scale.to(d), eps)
+    assert_mostly_exact(out, ref_q, 1, 5e-3, "fp8 out")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("hidden", [64, 1026, 5120, 8192])   # 1026: not a multiple of 4/8
+@pytest.mark.parametrize("tokens", [1, 7, 83])
+@pytest.mark.parametrize("add_residual", [False, True])
+@pytest.mark.parametrize("use_ub", [False, True])
+def test_rms_norm_dynamic_per_token_quant(dtype, hidden, tokens, add_residual, use_ub):
+    torch.manual_seed(0)
+    eps = 1e-6
+    w = (torch.randn(hidden) * 0.2 + 1.0).to(dtype)
+    x = (torch.randn(tokens, hidden) * 3).to(dtype)
+    res = torch.randn(tokens, hidden).to(dtype) if add_residual else None
+    ub = torch.tensor([2.5], dtype=torch.float32) if use_ub else None
+    ref_q, ref_s, ref_res = R.rms_norm_dynamic_per_token_quant(x, w, eps, ub, res)
+    d = dev()
+    out = torch.empty(tokens, hidden, dtype=torch.float8_e4m3fn, device=d)
+    scales = torch.empty(tokens, 1, dtype=torch.float32, device=d)
+    rd = res.to(d) if add_residual else None
+    ops().rms_norm_dynamic_per_token_quant(out, x.to(d), w.to(d), scales, eps,
+                                           ub.to(d) if use_ub else None, rd)
+    assert_close_rel(scales, ref_s, 1e-6, "scales")
+    if add_residual:
+        assert_bit_exact(rd, ref_res, "residual")
+    assert_mostly_exact(out, ref_q, 1, 5e-3, "fp8 out")
+
+
+# -------------------------------------------------------------------------- fp8 quant
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hidden", [17, 1024, 5137, 8192])
+@pytest.mark.parametrize("tokens", [1, 7, 4096 // 64])
+def test_fp8_quant(dtype, hidden, tokens):
+    torch.manual_seed(0)
+    x = (torch.rand(tokens, hidden) * 200 - 100).to(dtype)
+    x[0, 0] = 1e4 if dtype != torch.float16 else 6e4  # saturation path
+    d = dev()
+    xd = x.to(d)
+    # static
+    scale = torch.tensor([0.3], dtype=torch.float32)
+    out = torch.empty(tokens, hidden, dtype=torch.float8_e4m3fn, device=d)
+    ops().static_scaled_fp8_quant(out, xd, scale.to(d))
+    assert_bit_exact(out, R.static_scaled_fp8_quant(x, scale), "static")
+    # dynamic per tensor (scale zero-initialised by the caller)
+    sd = torch.zeros(1, dtype=torch.float32, device=d)
+    ops().dynamic_scaled_fp8_quant(out, xd, sd)
+    ref_q, ref_s = R.dynamic_scaled_fp8_quant(x)
+    assert_bit_exact(sd, ref_s, "dynamic scale")
+    assert_bit_exact(out, ref_q, "dynamic")
+    # dynamic per token, with and without an upper bound
+    for ub in (None, torch.tensor([60.0], dtype=torch.float32)):
+        st = torch.empty(tokens, 1, dtype=torch.float32, device=d)
+        ops().dynamic_per_token_scaled_fp8_quant(out, xd, st, ub.to(d) if ub is not None else None)
+        ref_q, ref_s = R.dynamic_per_token_scaled_fp8_quant(x, ub)
+        assert_bit_exact(st, ref_s, "per-token scales")
+        assert_mostly_exact(out, ref_q, 1, 1e-3, "per-token")  # x/s: division rounding only
+
+
+def test_fp8_quant_strided_rows():
+    torch.manual_seed(0)
+    x = torch.randn(9, 2 * 512).to(torch.bfloat16)
+    d = dev()
+    xd = x.to(d)[:, :512]
+    out = torch.empty(9, 512, dtype=torch.float8_e4m3fn, device=d)
+    scale = torch.tensor([0.01], dtype=torch.float32)
+    ops().static_scaled_fp8_quant(out, xd, scale.to(d))
+    assert_bit_exact(out, R.static_scaled_fp8_quant(x[:, :512], scale), "strided static")
+
+
+# ----------------------------------------------------------------------------- rotary
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("is_neox", [True, False])
+@pytest.mark.parametrize("head_size,rot_dim", [(64, 64), (80, 80), (128, 128), (128, 64), (256, 32), (120, 120)])
+@pytest.mark.parametrize("use_key", [True, False])
+def test_rotary_embedding(dtype, is_neox, head_size, rot_dim, use_key):
+    torch.manual_seed(0)
+    T, H, KVH, max_pos = 11 * 3, 8, 2, 8192
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, rot_dim, 2).float() / rot_dim))
+    t = torch.arange(max_pos).float()
+    freqs = torch.outer(t, inv_freq)
+    cache = torch.cat([freqs.cos(), freqs.sin()], dim=-1).to(dtype)
+    positions = torch.randint(0, max_pos, (T,), dtype=torch.int64)
+    qkv = torch.randn(T, (H + 2 * KVH) * head_size).to(dtype)
+    q = qkv[:, :H * head_size]                                   # strided views of a fused qkv
+    k = qkv[:, H * head_size:(H + KVH) * head_size] if use_key else None
+    ref_q, ref_k = R.rotary_embedding(positions, q, k, head_size, cache, is_neox)
+    d = dev()
+    qkv_d = qkv.to(d)
+    qd = qkv_d[:, :H * head_size]
+    kd = qkv_d[:, H * head_size:(H + KVH) * head_size] if use_key else None
+    ops().rotary_embedding(positions.to(d), qd, kd, head_size, cache.to(d), is_neox)
+    if dtype == torch.float32:
+        assert_close_rel(qd, ref_q, 1e-6, "q")
+        if use_key:
+            assert_close_rel(kd, ref_k, 1e-6, "k")
+    else:
+        assert_bit_exact(qd.contiguous(), ref_q.contiguous(), "q")
+        if use_key:
+            assert_bit_exact(kd.contiguous(), ref_k.contiguous(), "k")
+    # the value slice of the fused tensor must be untouched
+    assert_bit_exact(qkv_d[:, (H + KVH) * head_size:].contiguous(),
+                     qkv[:, (H + KVH) * head_size:].contiguous(), "v untouched")
+
+
+def test_rotary_embedding_3d_and_batched_positions():
+    torch.manual_seed(0)
+    B, L, H, hs = 2, 5, 4, 128
+    cache = torch.randn(64, hs).to(torch.bfloat16)
+    positions = torch.randint(0, 64, (B, L), dtype=torch.int64)
+    q = torch.randn(B, L, H, hs).to(torch.bfloat16)
+    k = torch.randn(B, L, H, hs).to(torch.bfloat16)
+    ref_q, ref_k = R.rotary_embedding(positions, q, k, hs, cache, True)
+    d = dev()
+    qd, kd = q.to(d), k.to(d)
+    ops().rotary_embedding(positions.to(d), qd, kd, hs, cache.to(d), True)
+    assert_bit_exact(qd, ref_q, "q")
+    assert_bit_exact(kd, ref_k, "k")
+
+
+# ------------------------------------------------------------------------- activation
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("d_", [13, 512, 2048, 14336])
+@pytest.mark.parametrize("tokens", [1, 7, 83])
+def test_silu_and_mul(dtype, d_, tokens):
+    torch.manual_seed(0)
+    x = torch.randn(tokens, 2 * d_).to(dtype)
+    ref = R.silu_and_mul(x)
+    d = dev()
+    out = torch.empty(tokens, d_, dtype=dtype, device=d)
+    ops().silu_and_mul(out, x.to(d))
+    if dtype == torch.float32:
+        assert_close_rel(out, ref, 1e-6, "silu_and_mul")
+    else:
+        # __expf vs torch.exp can differ by an fp32 ulp -> rare 1-ulp flips after rounding
+        assert_mostly_exact(out, ref, 1, 2e-3, "silu_and_mul")

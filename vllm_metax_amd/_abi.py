@@ -1,0 +1,91 @@
+"""ctypes binding of the C-ABI declared in include/mi355x_hotpath.h.
+
+This module only loads the library and declares prototypes; it performs no
+compute at import.  The product path fails loudly (ImportError / RuntimeError) when
+the HIP library has not been built — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "libmi355x_hotpath.so"
+
+F16, BF16, F32 = 0, 1, 2
+
+_P = c_void_p
+_I = c_int
+_L = c_int64
+_F = c_float
+
+# name -> (restype, argtypes); kept in the same order as the header.
+PROTOTYPES = {
+    "mi355x_abi_version": (_I, []),
+    "mi355x_last_error": (c_char_p, []),
+    "mi355x_get_device_attribute": (_L, [_L, _L]),
+    "mi355x_get_max_shared_memory_per_block_device_attribute": (_L, [_L]),
+    "mi355x_reshape_and_cache": (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "mi355x_reshape_and_cache_flash": (
+        _I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P]),
+    "mi355x_copy_blocks": (_I, [_P, _P, _I, _P, _I, _L, _P]),
+    "mi355x_swap_blocks": (_I, [_P, _P, _P, _I, _L, _I, _P]),
+    "mi355x_paged_attention_v1": (
+        _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _L, _L, _L, _I, _P]),
+    "mi355x_paged_attention_v2": (
+        _I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _L, _L, _L,
+             _I, _P]),
+    "mi355x_paged_prefill_attention": (
+        _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _I, _L, _L, _L, _L, _I, _P]),
+    "mi355x_rms_norm": (_I, [_P, _P, _P, _F, _I, _I, _L, _I, _P]),
+    "mi355x_fused_add_rms_norm": (_I, [_P, _P, _P, _F, _I, _I, _L, _I, _P]),
+    "mi355x_rms_norm_static_fp8_quant": (_I, [_P, _P, _P, _P, _F, _I, _I, _L, _I, _P]),
+    "mi355x_fused_add_rms_norm_static_fp8_quant": (
+        _I, [_P, _P, _P, _P, _P, _F, _I, _I, _L, _I, _P]),
+    "mi355x_rms_norm_dynamic_per_token_quant": (
+        _I, [_P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
+    "mi355x_static_scaled_fp8_quant": (_I, [_P, _P, _P, _I, _I, _L, _L, _I, _P]),
+    "mi355x_dynamic_scaled_fp8_quant": (_I, [_P, _P, _P, _I, _I, _L, _L, _I, _P]),
+    "mi355x_dynamic_per_token_scaled_fp8_quant": (_I, [_P, _P, _P, _P, _I, _I, _L, _L, _I, _P]),
+    "mi355x_rotary_embedding": (
+        _I, [_P, _P, _P, _P, _I, _I, _L, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "mi355x_silu_and_mul": (_I, [_P, _P, _I, _I, _I, _P]),
+    "mi355x_awq_to_gptq_4bit": (_I, [_P, _P, _I, _I, _P]),
+    "mi355x_awq_dequantize": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "mi355x_awq_gemm": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _P]),
+    "mi355x_gptq_shuffle": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mi355x_gptq_gemm": (
+        _I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "mi355x_scaled_mm_fp8": (
+        _I, [_P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _L, _L, _L, _I, _P]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libmi355x_hotpath.so (once) and attach prototypes to every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m vllm_metax_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().mi355x_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {last_error()}")

@@ -1,0 +1,546 @@
+"""Python op surface of the MI355X hot path.
+
+Mirrors, name for name and argument for argument, the ops the reference exposes
+through ``torch.ops._C`` / ``torch.ops._C_cache_ops`` (schemas:
+/root/reference csrc/torch_bindings.cpp:45-69,112-113,154-163,188-209,215-219,233-247,
+251-256,313-322,327-345,379-411,461-468) and its own wrappers
+``vllm_metax/_custom_ops.py:7-62`` (awq_gemm, awq_to_gptq_4bit, gptq_gemm,
+gptq_shuffle).  Every function extracts raw pointers / strides from the torch tensors
+and calls the C-ABI (include/mi355x_hotpath.h) on torch's current HIP stream — torch
+is plumbing only.  Errors surface as RuntimeError, like the reference's TORCH_CHECK.
+
+There is deliberately no CPU implementation here: calling an op without the built
+HIP library, or with CPU tensors, raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _abi
+
+_DT = {torch.float16: _abi.F16, torch.bfloat16: _abi.BF16, torch.float32: _abi.F32}
+PARTITION_SIZE = 512  # == MI355X_PA_PARTITION_SIZE (paged_attention_v2.cu:45)
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t.dtype}") from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr() or None
+
+
+def _dev(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("expected a tensor on the GPU (hip) device, got " + str(t.device))
+
+
+def _check_kv_dtype(kv_cache_dtype: str) -> None:
+    # ref: csrc/quantization/fp8/metax/quant_utils.cuh:29-42 — only "auto" is accepted
+    if kv_cache_dtype != "auto":
+        raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+
+
+# ----------------------------------------------------------------------------- utils
+def get_device_attribute(attribute: int, device_id: int) -> int:
+    v = _abi.load().mi355x_get_device_attribute(attribute, device_id)
+    if v < 0:
+        raise RuntimeError(_abi.last_error())
+    return v
+
+
+def get_max_shared_memory_per_block_device_attribute(device_id: int) -> int:
+    v = _abi.load().mi355x_get_max_shared_memory_per_block_device_attribute(device_id)
+    if v < 0:
+        raise RuntimeError(_abi.last_error())
+    return v
+
+
+# ------------------------------------------------------------------------- cache ops
+def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
+                      value_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                      kv_cache_dtype: str = "auto", k_scale: Optional[torch.Tensor] = None,
+                      v_scale: Optional[torch.Tensor] = None) -> None:
+    _check_kv_dtype(kv_cache_dtype)
+    _dev(key, value, key_cache, value_cache, slot_mapping)
+    if slot_mapping.dtype != torch.int64:
+        raise RuntimeError("slot_mapping must be int64")
+    num_tokens = slot_mapping.size(0)
+    num_heads, head_size = key.size(1), key.size(2)
+    block_size, x = key_cache.size(3), key_cache.size(4)
+    rc = _abi.load().mi355x_reshape_and_cache(
+        _ptr(key), _ptr(value), _ptr(key_cache), _ptr(value_cache), _ptr(slot_mapping),
+        num_tokens, key.stride(0), value.stride(0), num_heads, head_size, block_size, x,
+        _dt(key), _stream())
+    _abi.check(rc, "reshape_and_cache")
+
+
+def reshape_and_cache_flash(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
+                            value_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                            kv_cache_dtype: str = "auto",
+                            k_scale: Optional[torch.Tensor] = None,
+                            v_scale: Optional[torch.Tensor] = None) -> None:
+    _check_kv_dtype(kv_cache_dtype)
+    _dev(key, value, key_cache, value_cache, slot_mapping)
+    if slot_mapping.dtype != torch.int64:
+        raise RuntimeError("slot_mapping must be int64")
+    if key_cache.stride(0) != value_cache.stride(0):
+        raise RuntimeError("key_cache.stride(0) != value_cache.stride(0)")
+    num_tokens = slot_mapping.size(0)  # key may be longer (graph padding)
+    rc = _abi.load().mi355x_reshape_and_cache_flash(
+        _ptr(key), _ptr(value), _ptr(key_cache), _ptr(value_cache), _ptr(slot_mapping),
+        num_tokens, key_cache.stride(0), key_cache.stride(1), key_cache.stride(2),
+        key.stride(0), value.stride(0), key.size(1), key.size(2), key_cache.size(1),
+        _dt(key), _stream())
+    _abi.check(rc, "reshape_and_cache_flash")
+
+
+def copy_blocks(key_caches: Sequence[torch.Tensor], value_caches: Sequence[torch.Tensor],
+                block_mapping: torch.Tensor) -> None:
+    n = len(key_caches)
+    if n != len(value_caches):
+        raise RuntimeError("copy_blocks: key_caches and value_caches differ in length")
+    if n == 0:
+        return
+    _dev(*key_caches, *value_caches, block_mapping)
+    if block_mapping.dtype != torch.int64:
+        raise RuntimeError("block_mapping must be int64")
+    kp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in key_caches])
+    vp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in value_caches])
+    bytes_per_block = key_caches[0][0].numel() * key_caches[0].element_size()
+    bm = block_mapping.contiguous()
+    rc = _abi.load().mi355x_copy_blocks(kp, vp, n, _ptr(bm), bm.size(0), bytes_per_block,
+                                        _stream())
+    _abi.check(rc, "copy_blocks")
+
+
+def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tensor) -> None:
+    if block_mapping.device.type != "cpu":
+        raise RuntimeError("block_mapping must be on CPU")
+    if src.is_cuda and dst.is_cuda:
+        if src.device != dst.device:
+            raise RuntimeError("src and dst must be on the same GPU")
+        kind = 0
+    elif src.is_cuda and dst.device.type == "cpu":
+        kind = 1
+    elif src.device.type == "cpu" and dst.is_cuda:
+        kind = 2
+    else:
+        raise RuntimeError("Invalid device combination")
+    bm = block_mapping.to(torch.int64).contiguous()
+    block_bytes = src.element_size() * src.stride(0)
+    rc = _abi.load().mi355x_swap_blocks(_ptr(src), _ptr(dst), bm.data_ptr(), bm.size(0),
+                                        block_bytes, kind, _stream())
+    _abi.check(rc, "swap_blocks")
+
+
+# ------------------------------------------------------------------- paged attention
+def _check_blocksparse(blocksparse_vert_stride: int) -> None:
+    if blocksparse_vert_stride > 1:
+        raise RuntimeError("block-sparse paged attention is not supported by the MI355X plugin")
+
+
+def paged_attention_v1(out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                       value_cache: torch.Tensor, num_kv_heads: int, scale: float,
+                       block_tables: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
+                       max_seq_len: int, alibi_slopes: Optional[torch.Tensor],
+                       kv_cache_dtype: str = "auto", k_scale: Optional[torch.Tensor] = None,
+                       v_scale: Optional[torch.Tensor] = None, tp_rank: int = 0,
+                       blocksparse_local_blocks: int = 0, blocksparse_vert_stride: int = 0,
+                       blocksparse_block_size: int = 64,
+                       blocksparse_head_sliding_step: int = 0) -> None:
+    _check_kv_dtype(kv_cache_dtype)
+    _check_blocksparse(blocksparse_vert_stride)
+    _dev(out, query, key_cache, value_cache, block_tables, seq_lens, alibi_slopes)
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("block_tables and seq_lens must be int32")
+    rc = _abi.load().mi355x_paged_attention_v1(
+        _ptr(out), _ptr(query), _ptr(key_cache), _ptr(value_cache), query.size(0),
+        query.size(1), num_kv_heads, query.size(2), block_size, float(scale),
+        _ptr(block_tables), _ptr(seq_lens), block_tables.size(1), max_seq_len,
+        _ptr(alibi_slopes), query.stride(0), key_cache.stride(0), key_cache.stride(1),
+        _dt(query), _stream())
+    _abi.check(rc, "paged_attention_v1")
+
+
+def paged_attention_v2(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torch.Tensor,
+                       tmp_out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                       value_cache: torch.Tensor, num_kv_heads: int, scale: float,
+                       block_tables: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
+                       max_seq_len: int, alibi_slopes: Optional[torch.Tensor],
+                       kv_cache_dtype: str = "auto", k_scale: Optional[torch.Tensor] = None,
+                       v_scale: Optional[torch.Tensor] = None, tp_rank: int = 0,
+                       blocksparse_local_blocks: int = 0, blocksparse_vert_stride: int = 0,
+                       blocksparse_block_size: int = 64,
+                       blocksparse_head_sliding_step: int = 0) -> None:
+    _check_kv_dtype(kv_cache_dtype)
+    _check_blocksparse(blocksparse_vert_stride)
+    _dev(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, block_tables,
+         seq_lens, alibi_slopes)
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("block_tables and seq_lens must be int32")
+    rc = _abi.load().mi355x_paged_attention_v2(
+        _ptr(out), _ptr(exp_sums), _ptr(max_logits), _ptr(tmp_out), _ptr(query),
+        _ptr(key_cache), _ptr(value_cache), query.size(0), query.size(1), num_kv_heads,
+        query.size(2), block_size, float(scale), _ptr(block_tables), _ptr(seq_lens),
+        block_tables.size(1), max_seq_len, _ptr(alibi_slopes), query.stride(0),
+        key_cache.stride(0), key_cache.stride(1), _dt(query), _stream())
+    _abi.check(rc, "paged_attention_v2")
+
+
+def paged_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                            value_cache: torch.Tensor, num_kv_heads: int, scale: float,
+                            block_tables: torch.Tensor, seq_lens: torch.Tensor,
+                            cu_seqlens_q: torch.Tensor, max_query_len: int,
+                            block_size: int) -> None:
+    """Varlen causal attention of the new tokens against the paged cache (the role of
+    flash_attn_varlen_func(block_table=...) at the reference call site
+    vllm_metax/v1/attention/backends/flash_attn.py:725-747)."""
+    _dev(out, query, key_cache, value_cache, block_tables, seq_lens, cu_seqlens_q)
+    rc = _abi.load().mi355x_paged_prefill_attention(
+        _ptr(out), _ptr(query), _ptr(key_cache), _ptr(value_cache), seq_lens.size(0),
+        query.size(1), num_kv_heads, query.size(2), block_size, float(scale),
+        _ptr(block_tables), _ptr(seq_lens), _ptr(cu_seqlens_q), max_query_len,
+        block_tables.size(1), query.stride(0), out.stride(0), key_cache.stride(0),
+        key_cache.stride(1), _dt(query), _stream())
+    _abi.check(rc, "paged_prefill_attention")
+
+
+# ------------------------------------------------------------------------- layernorm
+def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
+             epsilon: float) -> None:
+    _dev(out, input, weight)
+    if not out.is_contiguous():
+        raise RuntimeError("rms_norm: out must be contiguous")
+    if input.stride(-1) != 1 or weight.stride(-1) != 1:
+        raise RuntimeError("rms_norm: innermost stride must be 1")
+    hidden = input.size(-1)
+    num_tokens = input.numel() // hidden if hidden else 0
+    in_stride = input.stride(-2) if input.dim() >= 2 else hidden
+    rc = _abi.load().mi355x_rms_norm(_ptr(out), _ptr(input), _ptr(weight), float(epsilon),
+                                     num_tokens, hidden, in_stride, _dt(input), _stream())
+    _abi.check(rc, "rms_norm")
+
+
+def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                       epsilon: float) -> None:
+    _dev(input, residual, weight)
+    if not residual.is_contiguous() or not weight.is_contiguous():
+        raise RuntimeError("fused_add_rms_norm: residual and weight must be contiguous")
+    hidden = input.size(-1)
+    num_tokens = input.numel() // hidden if hidden else 0
+    in_stride = input.stride(-2) if input.dim() >= 2 else hidden
+    rc = _abi.load().mi355x_fused_add_rms_norm(_ptr(input), _ptr(residual), _ptr(weight),
+                                               float(epsilon), num_tokens, hidden, in_stride,
+                                               _dt(input), _stream())
+    _abi.check(rc, "fused_add_rms_norm")
+
+
+def _check_fp8(out: torch.Tensor) -> None:
+    if out.dtype != torch.float8_e4m3fn:
+        raise RuntimeError(f"expected a float8_e4m3fn output, got {out.dtype}")
+
+
+def rms_norm_static_fp8_quant(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor,
+                              scale: torch.Tensor, epsilon: float) -> None:
+    _dev(out, input, weight, scale)
+    _check_fp8(out)
+    if not out.is_contiguous():
+        raise RuntimeError("out must be contiguous")
+    hidden = input.size(-1)
+    num_tokens = input.numel() // hidden
+    in_stride = input.stride(-2) if input.dim() >= 2 else hidden
+    rc = _abi.load().mi355x_rms_norm_static_fp8_quant(
+        _ptr(out), _ptr(input), _ptr(weight), _ptr(scale), float(epsilon), num_tokens, hidden,
+        in_stride, _dt(input), _stream())
+    _abi.check(rc, "rms_norm_static_fp8_quant")
+
+
+def fused_add_rms_norm_static_fp8_quant(out: torch.Tensor, input: torch.Tensor,
+                                        residual: torch.Tensor, weight: torch.Tensor,
+                                        scale: torch.Tensor, epsilon: float) -> None:
+    _dev(out, input, residual, weight, scale)
+    _check_fp8(out)
+    if not out.is_contiguous() or not residual.is_contiguous():
+        raise RuntimeError("out and residual must be contiguous")
+    hidden = input.size(-1)
+    num_tokens = input.numel() // hidden
+    in_stride = input.stride(-2) if input.dim() >= 2 else hidden
+    rc = _abi.load().mi355x_fused_add_rms_norm_static_fp8_quant(
+        _ptr(out), _ptr(input), _ptr(residual), _ptr(weight), _ptr(scale), float(epsilon),
+        num_tokens, hidden, in_stride, _dt(input), _stream())
+    _abi.check(rc, "fused_add_rms_norm_static_fp8_quant")
+
+
+def rms_norm_dynamic_per_token_quant(out: torch.Tensor, input: torch.Tensor,
+                                     weight: torch.Tensor, scales: torch.Tensor,
+                                     epsilon: float, scale_ub: Optional[torch.Tensor] = None,
+                                     residual: Optional[torch.Tensor] = None) -> None:
+    _dev(out, input, weight, scales, scale_ub, residual)
+    _check_fp8(out)  # the int8 branch of the reference is out of scope
+    if not (out.is_contiguous() and input.is_contiguous()):
+        raise RuntimeError("out and input must be contiguous")
+    if scales.dtype != torch.float32:
+        raise RuntimeError("scales must be float32")
+    hidden = input.size(-1)
+    num_tokens = input.numel() // hidden
+    rc = _abi.load().mi355x_rms_norm_dynamic_per_token_quant(
+        _ptr(out), _ptr(input), _ptr(weight), _ptr(scales), float(epsilon), _ptr(scale_ub),
+        _ptr(residual), num_tokens, hidden, _dt(input), _stream())
+    _abi.check(rc, "rms_norm_dynamic_per_token_quant")
+
+
+# ------------------------------------------------------------------------- fp8 quant
+def _rows(t: torch.Tensor):
+    hidden = t.size(-1)
+    num_tokens = t.numel() // hidden if hidden else 0
+    stride = t.stride(-2) if t.dim() >= 2 else hidden
+    return num_tokens, hidden, stride
+
+
+def static_scaled_fp8_quant(out: torch.Tensor, input: torch.Tensor,
+                            scale: torch.Tensor) -> None:
+    _dev(out, input, scale)
+    _check_fp8(out)
+    if input.stride(-1) != 1 or out.stride(-1) != 1:
+        raise RuntimeError("last dimension must be contiguous")
+    n, h, s_in = _rows(input)
+    _, _, s_out = _rows(out)
+    rc = _abi.load().mi355x_static_scaled_fp8_quant(_ptr(out), _ptr(input), _ptr(scale), n, h,
+                                                    s_in, s_out, _dt(input), _stream())
+    _abi.check(rc, "static_scaled_fp8_quant")
+
+
+def dynamic_scaled_fp8_quant(out: torch.Tensor, input: torch.Tensor,
+                             scale: torch.Tensor) -> None:
+    """`scale` must be zero-initialised by the caller (as upstream's scaled_fp8_quant does)."""
+    _dev(out, input, scale)
+    _check_fp8(out)
+    if input.stride(-1) != 1 or out.stride(-1) != 1:
+        raise RuntimeError("last dimension must be contiguous")
+    n, h, s_in = _rows(input)
+    _, _, s_out = _rows(out)
+    rc = _abi.load().mi355x_dynamic_scaled_fp8_quant(_ptr(out), _ptr(input), _ptr(scale), n, h,
+                                                     s_in, s_out, _dt(input), _stream())
+    _abi.check(rc, "dynamic_scaled_fp8_quant")
+
+
+def dynamic_per_token_scaled_fp8_quant(out: torch.Tensor, input: torch.Tensor,
+                                       scales: torch.Tensor,
+                                       scale_ub: Optional[torch.Tensor] = None) -> None:
+    _dev(out, input, scales, scale_ub)
+    _check_fp8(out)
+    if input.stride(-1) != 1 or out.stride(-1) != 1:
+        raise RuntimeError("last dimension must be contiguous")
+    n, h, s_in = _rows(input)
+    _, _, s_out = _rows(out)
+    rc = _abi.load().mi355x_dynamic_per_token_scaled_fp8_quant(
+        _ptr(out), _ptr(input), _ptr(scales), _ptr(scale_ub), n, h, s_in, s_out, _dt(input),
+        _stream())
+    _abi.check(rc, "dynamic_per_token_scaled_fp8_quant")
+
+
+# ---------------------------------------------------------------------------- rotary
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor,
+                     key: Optional[torch.Tensor], head_size: int,
+                     cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    """ref launcher: csrc/pos_encoding_kernels.cu:133-213 (shape / stride handling)."""
+    _dev(positions, query, key, cos_sin_cache)
+    if positions.dtype != torch.int64:
+        raise RuntimeError("positions must be int64")
+    num_tokens = positions.numel()
+    pdim = positions.dim()
+    if pdim not in (1, 2):
+        raise RuntimeError("positions must have shape [num_tokens] or [batch_size, seq_len]")
+    if pdim == 1:
+        if query.size(0) != positions.size(0) or (key is not None and key.size(0) != positions.size(0)):
+            raise RuntimeError("query, key and positions must have the same number of tokens")
+    else:
+        if (query.size(0) != positions.size(0) or query.size(1) != positions.size(1)
+                or (key is not None and (key.size(0) != positions.size(0)
+                                         or key.size(1) != positions.size(1)))):
+            raise RuntimeError("query, key and positions must have the same batch_size and seq_len")
+    q_hidden = query.numel() // num_tokens
+    k_hidden = key.numel() // num_tokens if key is not None else 0
+    if q_hidden % head_size or k_hidden % head_size:
+        raise RuntimeError("hidden size must be a multiple of head_size")
+    num_heads = q_hidden // head_size
+    num_kv_heads = k_hidden // head_size if key is not None else num_heads
+    if num_heads % num_kv_heads:
+        raise RuntimeError("num_heads must be a multiple of num_kv_heads")
+    rot_dim = cos_sin_cache.size(1)
+    seq_dim_idx = pdim - 1
+    query_stride = query.stride(seq_dim_idx)
+    key_stride = key.stride(seq_dim_idx) if key is not None else 0
+    query_ndim = query.dim()
+    head_stride = query.stride(-2) if query_ndim == pdim + 2 else head_size
+    rc = _abi.load().mi355x_rotary_embedding(
+        _ptr(positions), _ptr(query), _ptr(key), _ptr(cos_sin_cache), num_tokens, rot_dim,
+        query_stride, key_stride, head_stride, num_heads, num_kv_heads, head_size,
+        1 if is_neox else 0, _dt(query), _stream())
+    _abi.check(rc, "rotary_embedding")
+
+
+# ------------------------------------------------------------------------ activation
+def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
+    _dev(out, input)
+    if not (out.is_contiguous() and input.is_contiguous()):
+        raise RuntimeError("silu_and_mul: tensors must be contiguous")
+    d = input.size(-1) // 2
+    num_tokens = input.numel() // input.size(-1) if d else 0
+    rc = _abi.load().mi355x_silu_and_mul(_ptr(out), _ptr(input), num_tokens, d, _dt(input),
+                                         _stream())
+    _abi.check(rc, "silu_and_mul")
+
+
+# ----------------------------------------------------------------- int4 weight-only
+def awq_to_gptq_4bit(qweight: torch.Tensor) -> torch.Tensor:
+    """ref: vllm_metax/_custom_ops.py:26-29; csrc/quantization/awq/gemm_kernels.cu:323-356.
+    Returns a tensor DECLARED [N, K/8] whose memory is [K/8, N] (the reference's quirk)."""
+    _dev(qweight)
+    if qweight.dtype != torch.int32 or not qweight.is_contiguous():
+        raise RuntimeError("awq_to_gptq_4bit: qweight must be a contiguous int32 tensor")
+    k, n = qweight.size(0), qweight.size(1) * 8
+    out = torch.zeros((n, (k + 7) // 8), dtype=qweight.dtype, device=qweight.device)
+    rc = _abi.load().mi355x_awq_to_gptq_4bit(_ptr(out), _ptr(qweight), k, n, _stream())
+    _abi.check(rc, "awq_to_gptq_4bit")
+    return out
+
+
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor,
+                   split_k_iters: int = 0, thx: int = 0, thy: int = 0) -> torch.Tensor:
+    _dev(qweight, scales, zeros)
+    k, n = qweight.size(0), qweight.size(1) * 8
+    group = k // scales.size(0)
+    out = torch.empty((k, n), dtype=scales.dtype, device=scales.device)
+    rc = _abi.load().mi355x_awq_dequantize(_ptr(out), _ptr(qweight), _ptr(scales), _ptr(zeros),
+                                           k, n, group, _dt(scales), _stream())
+    _abi.check(rc, "awq_dequantize")
+    return out
+
+
+def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
+             scales: torch.Tensor, split_k_iters: int, temp_space: torch.Tensor,
+             dtype_bf16: bool) -> torch.Tensor:
+    """ref: vllm_metax/_custom_ops.py:7-22 (note the (qzeros, scales) order of the wrapper)
+    -> torch.ops._C.awq_gemm(input, qweight, scales, qzeros, split_k_iters, temp_space, bf16)."""
+    _dev(input, qweight, qzeros, scales)
+    if dtype_bf16 != (input.dtype == torch.bfloat16):
+        raise RuntimeError("awq_gemm: dtype_bf16 does not match the input dtype")
+    if input.dim() != 2 or input.stride(1) != 1:
+        raise RuntimeError("awq_gemm: input must be [M, K] with unit inner stride")
+    m, k = input.shape
+    n = qweight.size(0)  # declared [N, K/8]
+    group = k // scales.size(0)
+    out = torch.empty((m, n), dtype=input.dtype, device=input.device)
+    ws = temp_space if (temp_space is not None and temp_space.is_cuda
+                        and temp_space.dtype == torch.float32 and temp_space.numel() > 0) else None
+    rc = _abi.load().mi355x_awq_gemm(_ptr(out), _ptr(input), _ptr(qweight), _ptr(scales),
+                                     _ptr(qzeros), _ptr(ws), ws.numel() if ws is not None else 0,
+                                     m, n, k, group, input.stride(0), _dt(input), _stream())
+    _abi.check(rc, "awq_gemm")
+    return out
+
+
+def gptq_shuffle(q_weight: torch.Tensor, q_perm: torch.Tensor, bit: int) -> None:
+    """ref: vllm_metax/_custom_ops.py:61-62; csrc/quantization/gptq/q_gemm.cu:2415-2423."""
+    _dev(q_weight)
+    perm = None
+    if q_perm is not None and q_perm.device.type != "meta" and q_perm.numel() > 0:
+        _dev(q_perm)
+        perm = q_perm.to(torch.int32).contiguous()
+    k = q_weight.size(0) * 32 // bit
+    n = q_weight.size(1)
+    scratch = torch.empty_like(q_weight) if perm is not None else None
+    rc = _abi.load().mi355x_gptq_shuffle(_ptr(q_weight), _ptr(perm), _ptr(scratch), k, n, bit,
+                                         _stream())
+    _abi.check(rc, "gptq_shuffle")
+
+
+def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor,
+              b_gptq_scales: torch.Tensor, b_g_idx: torch.Tensor, use_exllama: bool, bit: int,
+              group_size: int, perm_space: torch.Tensor, temp_space: torch.Tensor,
+              dtype_bf16: bool) -> torch.Tensor:
+    """ref: vllm_metax/_custom_ops.py:33-58; csrc/quantization/gptq/q_gemm.cu:2373-2413."""
+    _dev(a, b_q_weight, b_gptq_qzeros, b_gptq_scales)
+    if dtype_bf16 != (a.dtype == torch.bfloat16):
+        raise RuntimeError("gptq_gemm: dtype_bf16 does not match the input dtype")
+    if not use_exllama:
+        raise RuntimeError("gptq_gemm: only the exllama (shuffled) weight layout is supported")
+    if not a.is_contiguous():
+        raise RuntimeError("gptq_gemm: a must be contiguous")
+    m, k = a.shape
+    n = b_q_weight.size(1)
+    g_idx = None
+    if b_g_idx is not None and b_g_idx.device.type != "meta" and b_g_idx.numel() > 0:
+        g_idx = b_g_idx.to(torch.int32).contiguous()
+    pspace = None
+    if g_idx is not None:
+        if perm_space is not None and perm_space.is_cuda and perm_space.numel() >= m * k \
+                and perm_space.element_size() == 2:
+            pspace = perm_space
+        else:
+            pspace = torch.empty((m, k), dtype=a.dtype, device=a.device)
+    ws = temp_space if (temp_space is not None and temp_space.is_cuda
+                        and temp_space.dtype == torch.float32 and temp_space.numel() > 0) else None
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    rc = _abi.load().mi355x_gptq_gemm(_ptr(out), _ptr(a), _ptr(b_q_weight), _ptr(b_gptq_qzeros),
+                                      _ptr(b_gptq_scales), _ptr(g_idx), _ptr(pspace), _ptr(ws),
+                                      ws.numel() if ws is not None else 0, m, n, k, bit,
+                                      group_size, _dt(a), _stream())
+    _abi.check(rc, "gptq_gemm")
+    return out
+
+
+# -------------------------------------------------------------------------- fp8 GEMM
+def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:
+    """The reference returns False (scaled_mm_entry.cu:22-24); gfx950 has OCP-fp8 MFMA."""
+    return True
+
+
+def cutlass_scaled_mm(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
+                      a_scales: torch.Tensor, b_scales: torch.Tensor,
+                      bias: Optional[torch.Tensor] = None) -> None:
+    """Schema csrc/torch_bindings.cpp:251-256; checks follow scaled_mm_entry.cu:84-140."""
+    _dev(out, a, b, a_scales, b_scales, bias)
+    if a.dim() != 2 or b.dim() != 2 or out.dim() != 2:
+        raise RuntimeError("cutlass_scaled_mm: a, b, out must be 2-D")
+    if out.size(0) != a.size(0) or a.size(1) != b.size(0) or b.size(1) != out.size(1):
+        raise RuntimeError("cutlass_scaled_mm: shape mismatch")
+    if a.stride(1) != 1 or out.stride(1) != 1:
+        raise RuntimeError("cutlass_scaled_mm: a and out must be row-major")
+    if b.stride(0) != 1:
+        raise RuntimeError("cutlass_scaled_mm: b must be column-major")
+    if out.stride(0) % 16 or b.stride(1) % 16:
+        raise RuntimeError("cutlass_scaled_mm: 16-byte alignment required")
+    if a.dtype != torch.float8_e4m3fn or b.dtype != torch.float8_e4m3fn:
+        raise RuntimeError("cutlass_scaled_mm: only float8_e4m3fn operands are supported "
+                           "(the int8 branch is out of scope, SURVEY §8f-4)")
+    m, k = a.shape
+    n = b.size(1)
+    if a_scales.numel() not in (1, m) or b_scales.numel() not in (1, n):
+        raise RuntimeError("cutlass_scaled_mm: scales must be per-tensor or per-row/column")
+    if a_scales.dtype != torch.float32 or b_scales.dtype != torch.float32:
+        raise RuntimeError("cutlass_scaled_mm: scales must be float32")
+    if not (a_scales.is_contiguous() and b_scales.is_contiguous()):
+        raise RuntimeError("cutlass_scaled_mm: scales must be contiguous")
+    if bias is not None and (bias.numel() != n or not bias.is_contiguous() or bias.dtype != out.dtype):
+        raise RuntimeError("cutlass_scaled_mm: bad bias")
+    rc = _abi.load().mi355x_scaled_mm_fp8(
+        _ptr(out), _ptr(a), _ptr(b), _ptr(a_scales), a_scales.numel(), _ptr(b_scales),
+        b_scales.numel(), _ptr(bias), m, n, k, a.stride(0), b.stride(1), out.stride(0),
+        _dt(out), _stream())
+    _abi.check(rc, "cutlass_scaled_mm")

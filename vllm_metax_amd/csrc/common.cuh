@@ -1,0 +1,187 @@
+// common.cuh — wave64 / gfx950 helpers shared by the hot-path kernels.
+// Written for CDNA4 only: 64-lane wavefronts, DPP/permlane cross-lane ops,
+// native __bf16 / _Float16 conversions (v_cvt_pk_bf16_f32 on gfx950).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mi355x_hotpath.h"
+
+namespace mi355x {
+
+constexpr int kWave = 64;
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+
+// ---- error plumbing (host) -------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MI355X_REQUIRE(cond, code, ...)  \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::mi355x::set_error(__VA_ARGS__);  \
+      return (code);                     \
+    }                                    \
+  } while (0)
+
+// ---- scalar conversions ------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float to_f32(T v) {
+  return static_cast<float>(v);
+}
+// Round-to-nearest-even conversions (c10::BFloat16 / c10::Half semantics).
+template <typename T>
+__device__ __forceinline__ T from_f32(float v) {
+  return static_cast<T>(v);
+}
+
+// bf16 pair <-> float without going through the type system (used on packed loads)
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t packed) {
+  return __uint_as_float(packed << 16);
+}
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t packed) {
+  return __uint_as_float(packed & 0xffff0000u);
+}
+
+// `a op b` evaluated the way c10 scalar types do it: in float, then rounded to T.
+template <typename T>
+__device__ __forceinline__ T mul_t(T a, T b) {
+  return from_f32<T>(to_f32(a) * to_f32(b));
+}
+template <typename T>
+__device__ __forceinline__ T add_t(T a, T b) {
+  return from_f32<T>(to_f32(a) + to_f32(b));
+}
+template <typename T>
+__device__ __forceinline__ T sub_t(T a, T b) {
+  return from_f32<T>(to_f32(a) - to_f32(b));
+}
+
+// ---- 16-byte vector of T -----------------------------------------------------
+template <typename T>
+struct Vec16 {
+  static constexpr int N = 16 / sizeof(T);
+  union {
+    uint4 u;
+    T e[N];
+  };
+};
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> load16(const T* p) {
+  Vec16<T> v;
+  v.u = *reinterpret_cast<const uint4*>(p);
+  return v;
+}
+template <typename T>
+__device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
+  *reinterpret_cast<uint4*>(p) = v.u;
+}
+
+// ---- wave64 reductions -------------------------------------------------------
+// Butterfly over the lanes whose index differs in the bits of `mask_from..32`.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// Block-wide sum / max for blocks of up to 1024 threads (16 waves).
+// `smem` must hold >= 16 floats and is reusable after the call returns.
+template <bool IS_MAX>
+__device__ __forceinline__ float block_reduce(float v, float* smem) {
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  v = IS_MAX ? wave_max(v) : wave_sum(v);
+  if (nw == 1) return v;
+  __syncthreads();  // protect smem from a previous use
+  if (lane == 0) smem[wid] = v;
+  __syncthreads();
+  float r = IS_MAX ? -3.402823466e+38f : 0.f;
+  if (lane < nw) r = smem[lane];
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {
+    float o = __shfl_xor(r, m, 64);
+    r = IS_MAX ? fmaxf(r, o) : r + o;
+  }
+  return __shfl(r, 0, 64);
+}
+
+// ---- fp8 e4m3fn (OCP) ----------------------------------------------------------
+constexpr float kFp8Max = 448.0f;
+constexpr float kFp8MinScale = 1.0f / (448.0f * 512.0f);
+
+// clamp to +-448 then RNE convert (c10::Float8_e4m3fn static_cast semantics for
+// in-range values; NaN stays NaN).  ref: csrc/quantization/fp8/common.cuh:25-38.
+__device__ __forceinline__ uint8_t f32_to_fp8_sat(float x) {
+  float r = fmaxf(-kFp8Max, fminf(x, kFp8Max));
+  int packed = __builtin_amdgcn_cvt_pk_fp8_f32(r, r, 0, false);
+  return static_cast<uint8_t>(packed & 0xff);
+}
+__device__ __forceinline__ uint16_t f32x2_to_fp8x2_sat(float a, float b) {
+  float ra = fmaxf(-kFp8Max, fminf(a, kFp8Max));
+  float rb = fmaxf(-kFp8Max, fminf(b, kFp8Max));
+  int packed = __builtin_amdgcn_cvt_pk_fp8_f32(ra, rb, 0, false);
+  return static_cast<uint16_t>(packed & 0xffff);
+}
+
+// ---- dtype dispatch ------------------------------------------------------------
+#define MI355X_DISPATCH_FLOAT(dtype, ...)                                \
+  [&]() -> int {                                                         \
+    switch (dtype) {                                                     \
+      case MI355X_F16: {                                                 \
+        using scalar_t = ::mi355x::f16_t;                                \
+        return __VA_ARGS__();                                            \
+      }                                                                  \
+      case MI355X_BF16: {                                                \
+        using scalar_t = ::mi355x::bf16_t;                               \
+        return __VA_ARGS__();                                            \
+      }                                                                  \
+      case MI355X_F32: {                                                 \
+        using scalar_t = float;                                          \
+        return __VA_ARGS__();                                            \
+      }                                                                  \
+      default:                                                           \
+        ::mi355x::set_error("unsupported dtype id %d", (int)(dtype));    \
+        return MI355X_EUNSUPPORTED;                                      \
+    }                                                                    \
+  }()
+
+#define MI355X_DISPATCH_HALF(dtype, ...)                                     \
+  [&]() -> int {                                                             \
+    switch (dtype) {                                                         \
+      case MI355X_F16: {                                                     \
+        using scalar_t = ::mi355x::f16_t;                                    \
+        return __VA_ARGS__();                                                \
+      }                                                                      \
+      case MI355X_BF16: {                                                    \
+        using scalar_t = ::mi355x::bf16_t;                                   \
+        return __VA_ARGS__();                                                \
+      }                                                                      \
+      default:                                                               \
+        ::mi355x::set_error("dtype id %d: only f16/bf16 supported here",     \
+                            (int)(dtype));                                   \
+        return MI355X_EUNSUPPORTED;                                          \
+    }                                                                        \
+  }()
+
+inline int dtype_size(int dtype) { return dtype == MI355X_F32 ? 4 : 2; }
+
+}  // namespace mi355x

@@ -1,0 +1,282 @@
+// layernorm.hip — RMSNorm family for gfx950: one workgroup per token row, the row
+// is read from HBM exactly once (16 B per lane) and kept in registers as fp32
+// between the variance pass and the normalise/quantise pass.
+//
+// Rounding points follow the reference kernels exactly:
+//   rms_norm / fused_add_rms_norm      csrc/layernorm_kernels.cu:12-41, 47-137
+//     z = T(in + res) (fused only, rounded to T);  x = float(z)
+//     out = T( float(T(x * rsqrt(mean(x^2)+eps))) * float(w) )
+//   *_static_fp8_quant                 csrc/layernorm_quant_kernels.cu:20-164
+//     fp8 = sat_e4m3( float(out) * (1/scale) )
+//   rms_norm_dynamic_per_token_quant   csrc/quantization/fused_kernels/
+//     layernorm_utils.cuh:17-115 — x = float(in) + float(res) is NOT rounded before
+//     the norm; residual = T(x); scale = max(min(absmax,ub)/448, 1/(448*512));
+//     fp8 = sat_e4m3( float(out) / scale )   (true division).
+#include "common.cuh"
+
+namespace mi355x {
+
+enum NormOut { kOutT = 0, kOutFp8Static = 1, kOutFp8Dynamic = 2 };
+
+template <typename T, int V, int MAXC, bool FUSED_ADD, int OUT>
+__global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
+                                T* __restrict__ input, int64_t input_stride,
+                                T* __restrict__ residual, const T* __restrict__ weight,
+                                const float* __restrict__ scale_in,   // static scale
+                                float* __restrict__ scales_out,       // dynamic scales
+                                const float* __restrict__ scale_ub, float epsilon,
+                                int hidden_size) {
+  __shared__ float red[16];
+  __shared__ float s_bcast;
+  const int64_t row = blockIdx.x;
+  T* in_row = input + row * input_stride;
+  T* res_row = residual ? residual + row * hidden_size : nullptr;
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+
+  float x[MAXC][V];
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int idx = (c * nthreads + tid) * V;
+    if (idx < hidden_size) {
+      T iv[V];
+      T rv[V];
+      if constexpr (V > 1) {
+        *reinterpret_cast<uint4*>(iv) = *reinterpret_cast<const uint4*>(in_row + idx);
+        if (res_row) *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res_row + idx);
+      } else {
+        iv[0] = in_row[idx];
+        if (res_row) rv[0] = res_row[idx];
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float v = to_f32(iv[j]);
+        if (res_row) {
+          v += to_f32(rv[j]);
+          const T z = from_f32<T>(v);
+          rv[j] = z;
+          if constexpr (FUSED_ADD) v = to_f32(z);  // norm of the ROUNDED sum
+        }
+        x[c][j] = v;
+        ss += v * v;
+      }
+      if (res_row) {
+        if constexpr (V > 1) {
+          *reinterpret_cast<uint4*>(res_row + idx) = *reinterpret_cast<const uint4*>(rv);
+        } else {
+          res_row[idx] = rv[0];
+        }
+      }
+    }
+  }
+  ss = block_reduce<false>(ss, red);
+  const float inv_rms = rsqrtf(ss / hidden_size + epsilon);
+
+  // normalise (T rounding before and after the weight multiply)
+  float amax = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int idx = (c * nthreads + tid) * V;
+    if (idx < hidden_size) {
+      T wv[V];
+      if constexpr (V > 1) {
+        *reinterpret_cast<uint4*>(wv) = *reinterpret_cast<const uint4*>(weight + idx);
+      } else {
+        wv[0] = weight[idx];
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const T n = from_f32<T>(x[c][j] * inv_rms);
+        const T o = mul_t<T>(n, wv[j]);
+        x[c][j] = to_f32(o);
+        amax = fmaxf(amax, fabsf(x[c][j]));
+      }
+    }
+  }
+
+  float q_mul = 1.f;   // multiply (static) ...
+  float q_div = 1.f;   // ... or divide (dynamic)
+  if constexpr (OUT == kOutFp8Static) {
+    q_mul = 1.0f / *scale_in;
+  } else if constexpr (OUT == kOutFp8Dynamic) {
+    amax = block_reduce<true>(amax, red);
+    if (tid == 0) {
+      float s = scale_ub ? fminf(amax, *scale_ub) : amax;
+      s = fmaxf(s / kFp8Max, kFp8MinScale);
+      scales_out[row] = s;
+      s_bcast = s;
+    }
+    __syncthreads();
+    q_div = s_bcast;
+  }
+
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int idx = (c * nthreads + tid) * V;
+    if (idx < hidden_size) {
+      if constexpr (OUT == kOutT) {
+        // fused_add writes back into `input` (strided); rms_norm into `out` (dense)
+        T* dst = FUSED_ADD ? (in_row + idx)
+                           : (static_cast<T*>(out_v) + row * hidden_size + idx);
+        T ov[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) ov[j] = from_f32<T>(x[c][j]);  // exact: already T
+        if constexpr (V > 1) {
+          *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(ov);
+        } else {
+          dst[0] = ov[0];
+        }
+      } else {
+        uint8_t* dst = static_cast<uint8_t*>(out_v) + row * hidden_size + idx;
+        uint8_t q[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float y = (OUT == kOutFp8Static) ? x[c][j] * q_mul : x[c][j] / q_div;
+          q[j] = f32_to_fp8_sat(y);
+        }
+        if constexpr (V == 8) {
+          *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(q);
+        } else if constexpr (V == 4) {
+          *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(q);
+        } else {
+          dst[0] = q[0];
+        }
+      }
+    }
+  }
+}
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename T, bool FUSED_ADD, int OUT>
+static int launch_norm(void* out, T* input, int64_t input_stride, T* residual,
+                       const T* weight, const float* scale_in, float* scales_out,
+                       const float* scale_ub, float eps, int num_tokens, int hidden,
+                       hipStream_t s, const char* name) {
+  constexpr int V = 16 / sizeof(T);
+  const bool vec = (hidden % V == 0) && (input_stride % V == 0) && al16(input) &&
+                   al16(weight) && (!residual || al16(residual)) &&
+                   (OUT != kOutT || FUSED_ADD || al16(out)) &&
+                   (OUT == kOutT || (reinterpret_cast<uintptr_t>(out) % V == 0));
+  const int units = vec ? hidden / V : hidden;
+  int threads = num_tokens < 256 ? 1024 : 256;
+  const int need = ((units + 63) / 64) * 64;
+  if (threads > need) threads = need;
+  auto chunks = [&](int t) { return (units + t - 1) / t; };
+  const int maxc = vec ? 4 : 32;
+  while (chunks(threads) > maxc && threads < 1024) threads *= 2;
+  if (threads > 1024) threads = 1024;
+  MI355X_REQUIRE(chunks(threads) <= maxc, MI355X_EUNSUPPORTED,
+                 "%s: hidden_size %d too large (max %d)", name, hidden, maxc * 1024 * (vec ? V : 1));
+  const int c = chunks(threads);
+  dim3 grid(num_tokens), block(threads);
+#define LAUNCH_NORM(VV, CC)                                                              \
+  hipLaunchKernelGGL((rms_norm_kernel<T, VV, CC, FUSED_ADD, OUT>), grid, block, 0, s, out, \
+                     input, input_stride, residual, weight, scale_in, scales_out,         \
+                     scale_ub, eps, hidden)
+  if (vec) {
+    if (c <= 1) LAUNCH_NORM(V, 1);
+    else if (c <= 2) LAUNCH_NORM(V, 2);
+    else LAUNCH_NORM(V, 4);
+  } else {
+    if (c <= 4) LAUNCH_NORM(1, 4);
+    else LAUNCH_NORM(1, 32);
+  }
+#undef LAUNCH_NORM
+  return check_launch(name);
+}
+
+}  // namespace mi355x
+
+using namespace mi355x;
+
+extern "C" {
+
+int mi355x_rms_norm(void* out, const void* input, const void* weight, float epsilon,
+                    int num_tokens, int hidden_size, int64_t input_stride, int dtype,
+                    mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && hidden_size > 0, MI355X_EINVAL, "rms_norm: bad sizes");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && input && weight, MI355X_EINVAL, "rms_norm: null pointer");
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    return launch_norm<scalar_t, false, kOutT>(
+        out, const_cast<scalar_t*>(static_cast<const scalar_t*>(input)), input_stride, nullptr,
+        static_cast<const scalar_t*>(weight), nullptr, nullptr, nullptr, epsilon, num_tokens,
+        hidden_size, static_cast<hipStream_t>(stream), "rms_norm");
+  });
+}
+
+int mi355x_fused_add_rms_norm(void* input, void* residual, const void* weight,
+                              float epsilon, int num_tokens, int hidden_size,
+                              int64_t input_stride, int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && hidden_size > 0, MI355X_EINVAL,
+                 "fused_add_rms_norm: bad sizes");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(input && residual && weight, MI355X_EINVAL,
+                 "fused_add_rms_norm: null pointer");
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    return launch_norm<scalar_t, true, kOutT>(
+        nullptr, static_cast<scalar_t*>(input), input_stride, static_cast<scalar_t*>(residual),
+        static_cast<const scalar_t*>(weight), nullptr, nullptr, nullptr, epsilon, num_tokens,
+        hidden_size, static_cast<hipStream_t>(stream), "fused_add_rms_norm");
+  });
+}
+
+int mi355x_rms_norm_static_fp8_quant(void* out, const void* input, const void* weight,
+                                     const float* scale, float epsilon, int num_tokens,
+                                     int hidden_size, int64_t input_stride, int dtype,
+                                     mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && hidden_size > 0, MI355X_EINVAL,
+                 "rms_norm_static_fp8_quant: bad sizes");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && input && weight && scale, MI355X_EINVAL,
+                 "rms_norm_static_fp8_quant: null pointer");
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    return launch_norm<scalar_t, false, kOutFp8Static>(
+        out, const_cast<scalar_t*>(static_cast<const scalar_t*>(input)), input_stride, nullptr,
+        static_cast<const scalar_t*>(weight), scale, nullptr, nullptr, epsilon, num_tokens,
+        hidden_size, static_cast<hipStream_t>(stream), "rms_norm_static_fp8_quant");
+  });
+}
+
+int mi355x_fused_add_rms_norm_static_fp8_quant(void* out, void* input, void* residual,
+                                               const void* weight, const float* scale,
+                                               float epsilon, int num_tokens,
+                                               int hidden_size, int64_t input_stride,
+                                               int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && hidden_size > 0, MI355X_EINVAL,
+                 "fused_add_rms_norm_static_fp8_quant: bad sizes");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && input && residual && weight && scale, MI355X_EINVAL,
+                 "fused_add_rms_norm_static_fp8_quant: null pointer");
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    return launch_norm<scalar_t, true, kOutFp8Static>(
+        out, static_cast<scalar_t*>(input), input_stride, static_cast<scalar_t*>(residual),
+        static_cast<const scalar_t*>(weight), scale, nullptr, nullptr, epsilon, num_tokens,
+        hidden_size, static_cast<hipStream_t>(stream), "fused_add_rms_norm_static_fp8_quant");
+  });
+}
+
+int mi355x_rms_norm_dynamic_per_token_quant(void* out, const void* input,
+                                            const void* weight, float* scales,
+                                            float epsilon, const float* scale_ub,
+                                            void* residual, int num_tokens,
+                                            int hidden_size, int dtype,
+                                            mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && hidden_size > 0, MI355X_EINVAL,
+                 "rms_norm_dynamic_per_token_quant: bad sizes");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && input && weight && scales, MI355X_EINVAL,
+                 "rms_norm_dynamic_per_token_quant: null pointer");
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    // FUSED_ADD=false: the norm uses the UNROUNDED fp32 sum (layernorm_utils.cuh:101-107)
+    return launch_norm<scalar_t, false, kOutFp8Dynamic>(
+        out, const_cast<scalar_t*>(static_cast<const scalar_t*>(input)), hidden_size,
+        static_cast<scalar_t*>(residual), static_cast<const scalar_t*>(weight), nullptr, scales,
+        scale_ub, epsilon, num_tokens, hidden_size, static_cast<hipStream_t>(stream),
+        "rms_norm_dynamic_per_token_quant");
+  });
+}
+
+}  // extern "C"

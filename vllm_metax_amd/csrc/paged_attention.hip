@@ -1,0 +1,604 @@
+// paged_attention.hip — single-query (decode) attention over the paged KV cache,
+// hand-written for gfx950 (wave64, v_dot2c_f32_{bf16,f16}, DPP/permlane shuffles).
+//
+// Reference semantics restated (order of operations and rounding points):
+//   csrc/attention/attention_kernels.cuh:75-485  (paged_attention_kernel)
+//     logits fp32 = scale * <q,k> (+ alibi_slope * (tok - seq_len + 1)); masked
+//     tokens excluded from the max; p = exp(l - max) * 1/(sum + 1e-6);
+//     p rounded to scalar_t BEFORE the PV product; PV accumulated in fp32;
+//     tail-block V lanes zeroed.
+//   :519-551 (v2 partition wrapper: PARTITION_SIZE = 512, per-partition max / sum,
+//     tmp_out in scalar_t), :553-658 (reduce: exp_sums[j]*exp(max_j-max), 1/(S+1e-6)).
+//   csrc/attention/paged_attention_v1.cu:43-125, paged_attention_v2.cu:43-131.
+//
+// MI355X design (not the reference's):
+//   * grid = (kv_head x head_tile, seq, partition); ONE workgroup serves up to GT=4
+//     query heads of a KV head, so every K/V byte is read from HBM once per GQA
+//     group instead of once per query head (4x fewer bytes on Llama-3).
+//   * the x-split layout [blk, kvh, d/x, bs, x] makes every 16-token K block a
+//     contiguous 4 KiB run: a wave fetches it with 16-B-per-lane loads whose 64
+//     lanes cover 1 KiB contiguous (lane = chunk_sub*BS + token), straight into
+//     VGPRs; V [blk, kvh, d, bs] likewise.  Two blocks are kept in flight per wave.
+//   * QK^T and PV are v_dot2c_f32_bf16 / _f16 on packed pairs (fp32 accumulate);
+//     the probabilities are stored in LDS already rounded to scalar_t, which is
+//     exactly the reference's rounding point.
+//   * reductions across the lanes that share a token are wave shuffles; across
+//     waves through LDS.
+#include "common.cuh"
+
+namespace mi355x {
+
+constexpr int kPaThreads = 256;
+constexpr int kPaWaves = kPaThreads / 64;
+constexpr int kPaScratchBytes = 128;  // red[16] + s_max[4] + s_sum[4], padded
+
+template <typename T>
+__device__ __forceinline__ float dot_chunk(const uint4& a, const uint4& b, float acc);
+
+template <>
+__device__ __forceinline__ float dot_chunk<bf16_t>(const uint4& a, const uint4& b, float acc) {
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.x),
+                                        __builtin_bit_cast(bf16x2_t, b.x), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.y),
+                                        __builtin_bit_cast(bf16x2_t, b.y), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.z),
+                                        __builtin_bit_cast(bf16x2_t, b.z), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.w),
+                                        __builtin_bit_cast(bf16x2_t, b.w), acc, false);
+  return acc;
+}
+template <>
+__device__ __forceinline__ float dot_chunk<f16_t>(const uint4& a, const uint4& b, float acc) {
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a.x), __builtin_bit_cast(f16x2_t, b.x),
+                               acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a.y), __builtin_bit_cast(f16x2_t, b.y),
+                               acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a.z), __builtin_bit_cast(f16x2_t, b.z),
+                               acc, false);
+  acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a.w), __builtin_bit_cast(f16x2_t, b.w),
+                               acc, false);
+  return acc;
+}
+template <>
+__device__ __forceinline__ float dot_chunk<float>(const uint4& a, const uint4& b, float acc) {
+  acc = fmaf(__uint_as_float(a.x), __uint_as_float(b.x), acc);
+  acc = fmaf(__uint_as_float(a.y), __uint_as_float(b.y), acc);
+  acc = fmaf(__uint_as_float(a.z), __uint_as_float(b.z), acc);
+  acc = fmaf(__uint_as_float(a.w), __uint_as_float(b.w), acc);
+  return acc;
+}
+
+// zero the elements of a 16-B V piece whose token index is >= seq_len
+template <typename T>
+__device__ __forceinline__ uint4 mask_tail(uint4 v, int first_token, int seq_len) {
+  constexpr int X = 16 / sizeof(T);
+  T e[X];
+  *reinterpret_cast<uint4*>(e) = v;
+#pragma unroll
+  for (int j = 0; j < X; ++j) {
+    if (first_token + j >= seq_len) e[j] = from_f32<T>(0.f);
+  }
+  return *reinterpret_cast<uint4*>(e);
+}
+
+// HS == 0: head size is a run-time value (any multiple of 16/sizeof(T) up to 256).
+template <typename T, int BS, int GT, int HS>
+__global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
+    float* __restrict__ exp_sums,    // [num_seqs, num_heads, P]       (partitioned only)
+    float* __restrict__ max_logits,  // [num_seqs, num_heads, P]       (partitioned only)
+    T* __restrict__ out,             // [num_seqs, num_heads, P, head_size]
+    const T* __restrict__ q,         // [num_seqs, num_heads, head_size]
+    const T* __restrict__ k_cache,   // [num_blocks, num_kv_heads, head_size/x, BS, x]
+    const T* __restrict__ v_cache,   // [num_blocks, num_kv_heads, head_size, BS]
+    int num_heads, int num_kv_heads, int head_size_rt, float scale,
+    const int* __restrict__ block_tables, const int* __restrict__ seq_lens,
+    int max_num_blocks_per_seq, const float* __restrict__ alibi_slopes, int64_t q_stride,
+    int64_t kv_block_stride, int64_t kv_head_stride, int partition_size, int logits_cap) {
+  constexpr int X = 16 / sizeof(T);
+  constexpr int LPT = 64 / BS;                 // lanes that share one token in QK
+  constexpr int TPP = BS / X;                  // 16-B pieces per V row
+  constexpr int DPI = 64 / TPP;                // V rows covered by one wave load
+  const int D = HS ? HS : head_size_rt;
+  const int C = D / X;                         // 16-B chunks per head vector
+  constexpr int NI = HS ? (HS / X + LPT - 1) / LPT : 0;   // K pieces per lane per block
+  constexpr int NIV = HS ? (HS + DPI - 1) / DPI : (256 + DPI - 1) / DPI;
+
+  const int seq = blockIdx.y;
+  const int part = blockIdx.z;
+  const int num_parts = gridDim.z;
+  const int seq_len = seq_lens[seq];
+  const bool partitioned = partition_size > 0;
+  if (partitioned && part * partition_size >= seq_len) return;
+
+  const int q_per_kv = num_heads / num_kv_heads;
+  const int tiles = (q_per_kv + GT - 1) / GT;
+  const int kv_head = blockIdx.x / tiles;
+  const int tile = blockIdx.x - kv_head * tiles;
+  const int head0 = kv_head * q_per_kv + tile * GT;       // first query head of this WG
+  const int nheads = min(GT, q_per_kv - tile * GT);       // valid heads in the tile
+
+  const int num_seq_blocks = (seq_len + BS - 1) / BS;
+  const int blocks_per_part = partitioned ? partition_size / BS : num_seq_blocks;
+  const int start_block = partitioned ? part * blocks_per_part : 0;
+  const int end_block = min(start_block + blocks_per_part, num_seq_blocks);
+  const int start_token = start_block * BS;
+  const int num_tokens = min(start_token + (end_block - start_block) * BS, seq_len) - start_token;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // all LDS lives in the dynamic region so that its base stays 16-B aligned
+  float* red = reinterpret_cast<float*>(smem);                          // [16]
+  float* s_max = red + 16;                                              // [4]
+  float* s_sum = red + 20;                                              // [4]
+  T* q_s = reinterpret_cast<T*>(smem + kPaScratchBytes);                // [GT][256]
+  float* logits =
+      reinterpret_cast<float*>(smem + kPaScratchBytes + (size_t)GT * 256 * sizeof(T));  // [GT][cap]
+  T* probs = reinterpret_cast<T*>(logits + (size_t)GT * logits_cap);    // [GT][cap]
+
+  // ---- stage q (packed scalar_t) into LDS; absent heads are zero ---------------
+  for (int i = tid; i < GT * C; i += kPaThreads) {
+    const int g = i / C;
+    const int c = i - g * C;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (g < nheads) {
+      v = *reinterpret_cast<const uint4*>(q + (int64_t)seq * q_stride + (int64_t)(head0 + g) * D + c * X);
+    }
+    *reinterpret_cast<uint4*>(q_s + g * D + c * X) = v;
+  }
+  __syncthreads();
+
+  float slope[GT];
+#pragma unroll
+  for (int g = 0; g < GT; ++g) {
+    slope[g] = (alibi_slopes != nullptr && g < nheads) ? alibi_slopes[head0 + g] : 0.f;
+  }
+
+  const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+
+  // =========================== QK^T ==============================================
+  const int t_in_blk = lane % BS;     // token of this lane inside a block
+  const int csub = lane / BS;         // chunk phase of this lane
+  float qk_max[GT];
+#pragma unroll
+  for (int g = 0; g < GT; ++g) qk_max[g] = -3.402823466e+38f;
+
+  if constexpr (HS != 0) {
+    // q chunks of this lane live in registers for the whole kernel
+    uint4 qreg[GT][NI];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = csub + LPT * i;
+        qreg[g][i] = (c < C) ? *reinterpret_cast<const uint4*>(q_s + g * D + c * X)
+                             : make_uint4(0, 0, 0, 0);
+      }
+    }
+    // two blocks per iteration and wave -> 2*NI 16-B loads in flight per lane
+    for (int blk = start_block + wave * 2; blk < end_block; blk += kPaWaves * 2) {
+      const bool has2 = (blk + 1) < end_block;
+      const int64_t pb0 = block_table[blk];
+      const int64_t pb1 = has2 ? block_table[blk + 1] : pb0;
+      const T* kp0 = k_cache + pb0 * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+      const T* kp1 = k_cache + pb1 * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+      uint4 k0[NI], k1[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = csub + LPT * i;
+        const int cc = (c < C) ? c : 0;
+        k0[i] = *reinterpret_cast<const uint4*>(kp0 + (cc * BS + t_in_blk) * X);
+        k1[i] = *reinterpret_cast<const uint4*>(kp1 + (cc * BS + t_in_blk) * X);
+      }
+      float a0[GT], a1[GT];
+#pragma unroll
+      for (int g = 0; g < GT; ++g) {
+        a0[g] = 0.f;
+        a1[g] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          a0[g] = dot_chunk<T>(k0[i], qreg[g][i], a0[g]);
+          a1[g] = dot_chunk<T>(k1[i], qreg[g][i], a1[g]);
+        }
+#pragma unroll
+        for (int m = BS; m < 64; m <<= 1) {
+          a0[g] += __shfl_xor(a0[g], m, 64);
+          a1[g] += __shfl_xor(a1[g], m, 64);
+        }
+      }
+      if (csub == 0) {
+        const int tok0 = blk * BS + t_in_blk;
+        const int tok1 = tok0 + BS;
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+          float v0 = a0[g] * scale;
+          float v1 = a1[g] * scale;
+          v0 += (slope[g] != 0.f) ? slope[g] * (tok0 - seq_len + 1) : 0.f;
+          v1 += (slope[g] != 0.f) ? slope[g] * (tok1 - seq_len + 1) : 0.f;
+          const bool m0 = tok0 >= seq_len;
+          logits[g * logits_cap + tok0 - start_token] = m0 ? 0.f : v0;
+          qk_max[g] = m0 ? qk_max[g] : fmaxf(qk_max[g], v0);
+          if (has2) {
+            const bool m1 = tok1 >= seq_len;
+            logits[g * logits_cap + tok1 - start_token] = m1 ? 0.f : v1;
+            qk_max[g] = m1 ? qk_max[g] : fmaxf(qk_max[g], v1);
+          }
+        }
+      }
+    }
+  } else {
+    for (int blk = start_block + wave; blk < end_block; blk += kPaWaves) {
+      const int64_t pb = block_table[blk];
+      const T* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+      float a[GT];
+#pragma unroll
+      for (int g = 0; g < GT; ++g) a[g] = 0.f;
+      for (int c = csub; c < C; c += LPT) {
+        const uint4 kv = *reinterpret_cast<const uint4*>(kp + (c * BS + t_in_blk) * X);
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+          const uint4 qv = *reinterpret_cast<const uint4*>(q_s + g * D + c * X);
+          a[g] = dot_chunk<T>(kv, qv, a[g]);
+        }
+      }
+      const int tok = blk * BS + t_in_blk;
+#pragma unroll
+      for (int g = 0; g < GT; ++g) {
+#pragma unroll
+        for (int m = BS; m < 64; m <<= 1) a[g] += __shfl_xor(a[g], m, 64);
+        if (csub == 0) {
+          float v = a[g] * scale;
+          v += (slope[g] != 0.f) ? slope[g] * (tok - seq_len + 1) : 0.f;
+          const bool msk = tok >= seq_len;
+          logits[g * logits_cap + tok - start_token] = msk ? 0.f : v;
+          qk_max[g] = msk ? qk_max[g] : fmaxf(qk_max[g], v);
+        }
+      }
+    }
+  }
+
+  // =========================== softmax ===========================================
+#pragma unroll
+  for (int g = 0; g < GT; ++g) {
+    const float m = block_reduce<true>(qk_max[g], red);
+    if (tid == 0) s_max[g] = m;
+  }
+  __syncthreads();
+  float lsum[GT];
+#pragma unroll
+  for (int g = 0; g < GT; ++g) {
+    lsum[g] = 0.f;
+    const float m = s_max[g];
+    for (int i = tid; i < num_tokens; i += kPaThreads) {
+      const float e = __expf(logits[g * logits_cap + i] - m);
+      logits[g * logits_cap + i] = e;
+      lsum[g] += e;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < GT; ++g) {
+    const float s = block_reduce<false>(lsum[g], red);
+    if (tid == 0) s_sum[g] = s;
+  }
+  __syncthreads();
+  const int padded_tokens = (end_block - start_block) * BS;
+#pragma unroll
+  for (int g = 0; g < GT; ++g) {
+    const float inv = __fdividef(1.f, s_sum[g] + 1e-6f);
+    for (int i = tid; i < padded_tokens; i += kPaThreads) {
+      const float p = (i < num_tokens) ? logits[g * logits_cap + i] * inv : 0.f;
+      probs[g * logits_cap + i] = from_f32<T>(p);
+    }
+  }
+  if (partitioned && tid < nheads) {
+    const int64_t o = ((int64_t)seq * num_heads + head0 + tid) * num_parts + part;
+    max_logits[o] = s_max[tid];
+    exp_sums[o] = s_sum[tid];
+  }
+  __syncthreads();
+
+  // =========================== P.V ===============================================
+  const int tq = lane % TPP;     // which 16-B piece (X tokens) of a V row
+  const int dsub = lane / TPP;   // V row phase
+  float oacc[GT][NIV];
+#pragma unroll
+  for (int g = 0; g < GT; ++g) {
+#pragma unroll
+    for (int i = 0; i < NIV; ++i) oacc[g][i] = 0.f;
+  }
+
+  auto pv_block = [&](int blk, const uint4 (&vv)[NIV]) {
+    uint4 pr[GT];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+      pr[g] = *reinterpret_cast<const uint4*>(probs + g * logits_cap + (blk - start_block) * BS + tq * X);
+    }
+#pragma unroll
+    for (int i = 0; i < NIV; ++i) {
+#pragma unroll
+      for (int g = 0; g < GT; ++g) oacc[g][i] = dot_chunk<T>(vv[i], pr[g], oacc[g][i]);
+    }
+  };
+
+  auto load_v = [&](int blk, uint4 (&vv)[NIV]) {
+    const int64_t pb = block_table[blk];
+    const T* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+    const bool last = (blk == num_seq_blocks - 1);
+#pragma unroll
+    for (int i = 0; i < NIV; ++i) {
+      const int d = dsub + DPI * i;
+      if (d < D) {
+        uint4 v = *reinterpret_cast<const uint4*>(vp + (int64_t)d * BS + tq * X);
+        if (last) v = mask_tail<T>(v, blk * BS + tq * X, seq_len);
+        vv[i] = v;
+      } else {
+        vv[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+
+  if constexpr (HS != 0) {
+    for (int blk = start_block + wave * 2; blk < end_block; blk += kPaWaves * 2) {
+      uint4 v0[NIV], v1[NIV];
+      const bool has2 = (blk + 1) < end_block;
+      load_v(blk, v0);
+      if (has2) load_v(blk + 1, v1);
+      pv_block(blk, v0);
+      if (has2) pv_block(blk + 1, v1);
+    }
+  } else {
+    for (int blk = start_block + wave; blk < end_block; blk += kPaWaves) {
+      uint4 v0[NIV];
+      load_v(blk, v0);
+      pv_block(blk, v0);
+    }
+  }
+
+  // lanes that hold the same V row (different token pieces) -> lane with tq == 0
+#pragma unroll
+  for (int g = 0; g < GT; ++g) {
+#pragma unroll
+    for (int i = 0; i < NIV; ++i) {
+#pragma unroll
+      for (int m = 1; m < TPP; m <<= 1) oacc[g][i] += __shfl_xor(oacc[g][i], m, 64);
+    }
+  }
+
+  // cross-wave sum through LDS (reuses the logits region)
+  __syncthreads();
+  float* osm = logits;  // [kPaWaves][GT][D]
+  if (tq == 0) {
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+#pragma unroll
+      for (int i = 0; i < NIV; ++i) {
+        const int d = dsub + DPI * i;
+        if (d < D) osm[(wave * GT + g) * D + d] = oacc[g][i];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < nheads * D; i += kPaThreads) {
+    const int g = i / D;
+    const int d = i - g * D;
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < kPaWaves; ++w) acc += osm[(w * GT + g) * D + d];
+    const int64_t o = (((int64_t)seq * num_heads + head0 + g) * num_parts + part) * D + d;
+    out[o] = from_f32<T>(acc);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// v2 reduce: grid (num_heads, num_seqs), 128 threads.
+// ref: csrc/attention/attention_kernels.cuh:553-658.
+template <typename T>
+__global__ __launch_bounds__(128) void paged_attention_reduce_kernel(
+    T* __restrict__ out, const float* __restrict__ exp_sums,
+    const float* __restrict__ max_logits, const T* __restrict__ tmp_out,
+    const int* __restrict__ seq_lens, int head_size, int max_num_partitions,
+    int partition_size) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_w = reinterpret_cast<float*>(smem);  // [max_num_partitions]
+  __shared__ float red[16];
+  __shared__ float s_inv;
+  const int head = blockIdx.x;
+  const int num_heads = gridDim.x;
+  const int seq = blockIdx.y;
+  const int seq_len = seq_lens[seq];
+  const int np = (seq_len + partition_size - 1) / partition_size;
+  const int64_t base = ((int64_t)seq * num_heads + head) * max_num_partitions;
+  T* o = out + ((int64_t)seq * num_heads + head) * head_size;
+  const T* tmp = tmp_out + base * head_size;
+  if (np == 1) {
+    for (int i = threadIdx.x; i < head_size; i += blockDim.x) o[i] = tmp[i];
+    return;
+  }
+  float m = -3.402823466e+38f;
+  for (int j = threadIdx.x; j < np; j += blockDim.x) m = fmaxf(m, max_logits[base + j]);
+  m = block_reduce<true>(m, red);
+  float s = 0.f;
+  for (int j = threadIdx.x; j < np; j += blockDim.x) {
+    const float w = exp_sums[base + j] * expf(max_logits[base + j] - m);
+    s_w[j] = w;
+    s += w;
+  }
+  s = block_reduce<false>(s, red);
+  if (threadIdx.x == 0) s_inv = __fdividef(1.0f, s + 1e-6f);
+  __syncthreads();
+  const float inv = s_inv;
+  for (int i = threadIdx.x; i < head_size; i += blockDim.x) {
+    float acc = 0.f;
+    for (int j = 0; j < np; ++j) acc += to_f32(tmp[(int64_t)j * head_size + i]) * s_w[j] * inv;
+    o[i] = from_f32<T>(acc);
+  }
+}
+
+struct PaArgs {
+  void* out;
+  float* exp_sums;
+  float* max_logits;
+  void* tmp_out;
+  const void* query;
+  const void* key_cache;
+  const void* value_cache;
+  int num_seqs, num_heads, num_kv_heads, head_size, block_size;
+  float scale;
+  const int* block_tables;
+  const int* seq_lens;
+  int max_num_blocks_per_seq, max_seq_len;
+  const float* alibi_slopes;
+  int64_t q_stride, kv_block_stride, kv_head_stride;
+  int partition_size;  // 0 => v1
+  hipStream_t stream;
+};
+
+template <typename T, int BS, int GT, int HS>
+static int launch_pa_inst(const PaArgs& a, int tiles, int num_parts, int logits_cap,
+                          size_t smem) {
+  auto kern = paged_attention_kernel<T, BS, GT, HS>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+      set_error("paged_attention: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+      return MI355X_EUNSUPPORTED;
+    }
+  }
+  dim3 grid(a.num_kv_heads * tiles, a.num_seqs, num_parts);
+  T* dst = static_cast<T*>(a.partition_size > 0 ? a.tmp_out : a.out);
+  hipLaunchKernelGGL(kern, grid, dim3(kPaThreads), smem, a.stream, a.exp_sums, a.max_logits, dst,
+                     static_cast<const T*>(a.query), static_cast<const T*>(a.key_cache),
+                     static_cast<const T*>(a.value_cache), a.num_heads, a.num_kv_heads,
+                     a.head_size, a.scale, a.block_tables, a.seq_lens,
+                     a.max_num_blocks_per_seq, a.alibi_slopes, a.q_stride, a.kv_block_stride,
+                     a.kv_head_stride, a.partition_size, logits_cap);
+  return check_launch("paged_attention");
+}
+
+template <typename T, int BS>
+static int launch_pa_bs(const PaArgs& a) {
+  constexpr int X = 16 / sizeof(T);
+  const int q_per_kv = a.num_heads / a.num_kv_heads;
+  const int gt = q_per_kv >= 3 ? 4 : q_per_kv;  // 1, 2 or 4 heads per workgroup
+  const int tiles = (q_per_kv + gt - 1) / gt;
+  const int padded_len = ((a.max_seq_len + BS - 1) / BS) * BS;
+  int logits_cap = a.partition_size > 0 ? a.partition_size : padded_len;
+  // the cross-wave output buffer [waves][GT][D] aliases the logits region
+  const int min_cap = kPaWaves * a.head_size;
+  if (logits_cap < min_cap) logits_cap = min_cap;
+  logits_cap = (logits_cap + 63) & ~63;
+  const size_t smem = kPaScratchBytes + (size_t)gt * 256 * sizeof(T) +
+                      (size_t)gt * logits_cap * (4 + sizeof(T));
+  MI355X_REQUIRE(smem <= 160 * 1024, MI355X_EUNSUPPORTED,
+                 "paged_attention_v1: max_seq_len %d needs %zu B of LDS (> 160 KiB); use "
+                 "paged_attention_v2",
+                 a.max_seq_len, smem);
+  const int num_parts =
+      a.partition_size > 0 ? (a.max_seq_len + a.partition_size - 1) / a.partition_size : 1;
+  const bool fast = (a.head_size == 128) && (BS == 16) && (sizeof(T) == 2);
+#define PA_CASE(GTV)                                                                   \
+  if (gt == GTV) {                                                                     \
+    if (fast) {                                                                        \
+      if constexpr (BS == 16 && sizeof(T) == 2)                                        \
+        return launch_pa_inst<T, BS, GTV, 128>(a, tiles, num_parts, logits_cap, smem); \
+    }                                                                                  \
+    return launch_pa_inst<T, BS, GTV, 0>(a, tiles, num_parts, logits_cap, smem);       \
+  }
+  PA_CASE(1)
+  PA_CASE(2)
+  PA_CASE(4)
+#undef PA_CASE
+  set_error("paged_attention: internal dispatch error");
+  return MI355X_EINVAL;
+}
+
+template <typename T>
+static int launch_pa(const PaArgs& a) {
+  switch (a.block_size) {
+    case 8: return launch_pa_bs<T, 8>(a);
+    case 16: return launch_pa_bs<T, 16>(a);
+    case 32: return launch_pa_bs<T, 32>(a);
+    default:
+      set_error("Unsupported block size: %d", a.block_size);
+      return MI355X_EUNSUPPORTED;
+  }
+}
+
+static int validate_pa(const PaArgs& a, const char* name) {
+  MI355X_REQUIRE(a.num_seqs >= 0 && a.num_heads > 0 && a.num_kv_heads > 0 && a.head_size > 0 &&
+                     a.max_num_blocks_per_seq >= 0 && a.max_seq_len >= 0,
+                 MI355X_EINVAL, "%s: bad sizes", name);
+  MI355X_REQUIRE(a.num_heads % a.num_kv_heads == 0, MI355X_EINVAL,
+                 "%s: num_heads %d not a multiple of num_kv_heads %d", name, a.num_heads,
+                 a.num_kv_heads);
+  switch (a.head_size) {  // ref: paged_attention_v1.cu:90-124
+    case 32: case 64: case 80: case 96: case 112: case 120: case 128: case 192: case 256: break;
+    default:
+      set_error("Unsupported head size: %d", a.head_size);
+      return MI355X_EUNSUPPORTED;
+  }
+  if (a.num_seqs == 0) return MI355X_OK;
+  MI355X_REQUIRE(a.out && a.query && a.key_cache && a.value_cache && a.block_tables && a.seq_lens,
+                 MI355X_EINVAL, "%s: null pointer", name);
+  MI355X_REQUIRE(a.num_seqs <= 65535, MI355X_EUNSUPPORTED, "%s: num_seqs %d > 65535", name,
+                 a.num_seqs);
+  return MI355X_OK;
+}
+
+}  // namespace mi355x
+
+using namespace mi355x;
+
+extern "C" {
+
+int mi355x_paged_attention_v1(void* out, const void* query, const void* key_cache,
+                              const void* value_cache, int num_seqs, int num_heads,
+                              int num_kv_heads, int head_size, int block_size,
+                              float scale, const int* block_tables,
+                              const int* seq_lens, int max_num_blocks_per_seq,
+                              int max_seq_len, const float* alibi_slopes,
+                              int64_t q_stride, int64_t kv_block_stride,
+                              int64_t kv_head_stride, int dtype, mi355x_stream stream) {
+  PaArgs a{out, nullptr, nullptr, nullptr, query, key_cache, value_cache, num_seqs, num_heads,
+           num_kv_heads, head_size, block_size, scale, block_tables, seq_lens,
+           max_num_blocks_per_seq, max_seq_len, alibi_slopes, q_stride, kv_block_stride,
+           kv_head_stride, 0, static_cast<hipStream_t>(stream)};
+  int rc = validate_pa(a, "paged_attention_v1");
+  if (rc || num_seqs == 0) return rc;
+  return MI355X_DISPATCH_FLOAT(dtype, [&] { return launch_pa<scalar_t>(a); });
+}
+
+int mi355x_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
+                              void* tmp_out, const void* query, const void* key_cache,
+                              const void* value_cache, int num_seqs, int num_heads,
+                              int num_kv_heads, int head_size, int block_size,
+                              float scale, const int* block_tables,
+                              const int* seq_lens, int max_num_blocks_per_seq,
+                              int max_seq_len, const float* alibi_slopes,
+                              int64_t q_stride, int64_t kv_block_stride,
+                              int64_t kv_head_stride, int dtype, mi355x_stream stream) {
+  PaArgs a{out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs,
+           num_heads, num_kv_heads, head_size, block_size, scale, block_tables, seq_lens,
+           max_num_blocks_per_seq, max_seq_len, alibi_slopes, q_stride, kv_block_stride,
+           kv_head_stride, MI355X_PA_PARTITION_SIZE, static_cast<hipStream_t>(stream)};
+  int rc = validate_pa(a, "paged_attention_v2");
+  if (rc || num_seqs == 0) return rc;
+  MI355X_REQUIRE(exp_sums && max_logits && tmp_out, MI355X_EINVAL,
+                 "paged_attention_v2: null workspace pointer");
+  rc = MI355X_DISPATCH_FLOAT(dtype, [&] { return launch_pa<scalar_t>(a); });
+  if (rc) return rc;
+  const int max_parts = (max_seq_len + MI355X_PA_PARTITION_SIZE - 1) / MI355X_PA_PARTITION_SIZE;
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    hipLaunchKernelGGL(paged_attention_reduce_kernel<scalar_t>, dim3(num_heads, num_seqs),
+                       dim3(128), (size_t)(max_parts > 0 ? max_parts : 1) * sizeof(float), a.stream,
+                       static_cast<scalar_t*>(out), exp_sums, max_logits,
+                       static_cast<const scalar_t*>(tmp_out), seq_lens, head_size, max_parts,
+                       MI355X_PA_PARTITION_SIZE);
+    return check_launch("paged_attention_v2_reduce");
+  });
+}
+
+}  // extern "C"
