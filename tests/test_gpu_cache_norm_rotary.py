@@ -8,7 +8,9 @@ tests: tests/kernels/attention/test_cache.py:13-40, tests/kernels/core/test_laye
 Tolerances (stated per SURVEY §8 / north_star):
   * cache / copy ops: bit-exact.
   * 16-bit normalised outputs: the only freedom is the fp32 summation order of the
-    variance, which can flip a final rounding: <= 1 ulp, on <= 0.5 % of the elements.
+    variance (and v_rsq_f32's last bit), which can flip the rounding of T(x*inv_rms) by
+    one ulp; the following T*T product can turn that into 2 ulp of the output:
+    <= 2 ulp, on <= 0.5 % of the elements.
   * fp8 outputs: <= 1 fp8 ulp on <= 0.5 % of elements; per-token scales rel 1e-6.
   * rotary / silu: bit-exact for 16-bit types (pure per-element arithmetic with the
     same rounding points); fp32 within 1e-6 relative (fma contraction).
@@ -168,7 +170,7 @@ def test_rms_norm(dtype, hidden, tokens, add_residual, strided):
     res = torch.randn(tokens, hidden).to(dtype) * 0 + (torch.randn(tokens, hidden) * (1.0 / (2 * hidden))).to(dtype)
     d = dev()
     xd = xfull.to(d)[..., :hidden]
-    frac, ulp = (5e-3, 1) if dtype != torch.float32 else (1.0, 64)
+    frac, ulp = (5e-3, 2) if dtype != torch.float32 else (1.0, 64)
     if add_residual:
         ref_out, ref_res = R.fused_add_rms_norm(x, res, w, eps)
         rd = res.to(d)

@@ -1,0 +1,174 @@
+"""GPU parity: AWQ / GPTQ int4 weight-only path against the CPU oracle.
+
+Integer ops (awq_to_gptq_4bit, gptq_shuffle incl. act-order make_sequential) and the
+dequantised weights (awq_dequantize) are bit-exact.  GEMM outputs: the dequantised
+weights are identical to the oracle's bit for bit, products are exact in fp32, so the
+only freedom is the fp32 accumulation order (MFMA k-order, split-K) before the single
+rounding of C to scalar_t:  max|err| <= 1e-3 * max|ref| (north_star bound) and, tighter,
+<= 1 ulp of the output type on <= 2 % of the elements.
+
+Shapes: scaled-down then full Llama-3-8B AWQ (K,N) from BASELINE.md §3, g = 128, M in
+{1, 7, 16, 33, 64, 100}; weights nibbles U{0..15}, zeros U{0..15}, scales U(1e-3, 1e-2).
+The reference has no numeric test for these native ops (tests/kernels/quantization/
+test_awq.py:11-47 and test_gptq.py:10-32 are opcheck-only): parity is pinned by the
+oracle's restatement plus tests/kernels/quantization/test_awq_triton.py's dequant reference.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import assert_bit_exact, assert_close_rel, assert_mostly_exact, dev
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_ops as R  # noqa: E402
+
+
+def ops():
+    from vllm_metax_amd import _custom_ops
+    return _custom_ops
+
+
+def make_awq(k, n, group, dtype, seed=0):
+    rng = np.random.default_rng(seed)
+    w = rng.integers(0, 16, size=(k, n), dtype=np.uint8)
+    z = rng.integers(0, 16, size=(k // group, n), dtype=np.uint8)
+    g = torch.Generator().manual_seed(seed)
+    scales = (torch.rand(k // group, n, generator=g) * 9e-3 + 1e-3).to(dtype)
+    return R.awq_pack(w), R.awq_pack(z), scales, w, z
+
+
+def make_gptq(k, n, group, dtype, seed=0, sym=False):
+    rng = np.random.default_rng(seed)
+    w = rng.integers(0, 16, size=(k, n), dtype=np.uint8)
+    z = np.full((k // group, n), 7, dtype=np.uint8) if sym else \
+        rng.integers(0, 15, size=(k // group, n), dtype=np.uint8)
+    g = torch.Generator().manual_seed(seed)
+    scales = (torch.rand(k // group, n, generator=g) * 9e-3 + 1e-3).to(dtype)
+    qz = torch.from_numpy(R._pack_nibbles(z.reshape(k // group, n // 8, 8)).view(np.int32))
+    return R.gptq_pack_rows(w), qz, scales
+
+
+@pytest.mark.parametrize("k,n", [(32, 64), (128, 256), (4096, 4096), (1000 * 8, 72 * 8)])
+def test_awq_to_gptq_4bit(k, n):
+    qw, _, _, _, _ = make_awq(k, n, k if k < 128 else 8 if k % 128 else 128, torch.float16)
+    ref = R.awq_to_gptq_4bit(qw)
+    out = ops().awq_to_gptq_4bit(qw.to(dev()))
+    assert out.shape == ref.shape == (n, k // 8)       # declared [N, K/8] (reference quirk)
+    assert_bit_exact(out, ref, "awq_to_gptq_4bit")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("k,n,group", [(128, 64, 32), (512, 256, 128), (4096, 1024, 128)])
+def test_awq_dequantize(dtype, k, n, group):
+    qw, qz, sc, _, _ = make_awq(k, n, group, dtype, seed=1)
+    ref = R.awq_dequantize(qw, sc, qz)
+    d = dev()
+    out = ops().awq_dequantize(qw.to(d), sc.to(d), qz.to(d), 0, 0, 0)
+    assert_bit_exact(out, ref, "awq_dequantize")
+
+
+@pytest.mark.parametrize("act_order", [False, True])
+@pytest.mark.parametrize("k,n", [(128, 64), (4096, 512)])
+def test_gptq_shuffle(k, n, act_order):
+    qw, _, _ = make_gptq(k, n, 128, torch.float16, seed=2)
+    perm = torch.randperm(k, generator=torch.Generator().manual_seed(3)).to(torch.int32) if act_order \
+        else torch.empty(0, dtype=torch.int32)
+    ref = R.gptq_shuffle(qw, perm)
+    d = dev()
+    qd = qw.to(d).clone()
+    ops().gptq_shuffle(qd, perm.to(d) if act_order else perm, 4)
+    assert_bit_exact(qd, ref, "gptq_shuffle")
+
+
+def _check_gemm(out, ref, what):
+    assert_close_rel(out, ref, 1e-3, what)
+    assert_mostly_exact(out, ref, 1, 2e-2, what)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m", [1, 7, 16, 33, 64, 100])
+@pytest.mark.parametrize("k,n,group", [(256, 128, 128), (1024, 768, 128), (512, 256, 32), (2048, 64, 64)])
+def test_awq_gemm_small_shapes(dtype, m, k, n, group):
+    qw, qz, sc, _, _ = make_awq(k, n, group, dtype, seed=4)
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(5)).to(dtype)
+    q2 = R.awq_to_gptq_4bit(qw)
+    ref = R.awq_gemm(x, q2, sc, qz)
+    d = dev()
+    q2d = ops().awq_to_gptq_4bit(qw.to(d))
+    ws = torch.zeros(m, n, dtype=torch.float32, device=d)
+    out = ops().awq_gemm(x.to(d), q2d, qz.to(d), sc.to(d), 8, ws, dtype == torch.bfloat16)
+    _check_gemm(out, ref, f"awq_gemm m={m}")
+    # without a workspace the kernel must not split K and give the same answer
+    out2 = ops().awq_gemm(x.to(d), q2d, qz.to(d), sc.to(d), 8, torch.empty(0), dtype == torch.bfloat16)
+    _check_gemm(out2, ref, f"awq_gemm (no workspace) m={m}")
+
+
+@pytest.mark.parametrize("k,n", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
+def test_awq_gemm_llama3_8b_decode_shapes(k, n):
+    """Full Llama-3-8B AWQ layer shapes at the decode batch M = 64."""
+    dtype, m, group = torch.bfloat16, 64, 128
+    qw, qz, sc, _, _ = make_awq(k, n, group, dtype, seed=6)
+    x = (torch.randn(m, k, generator=torch.Generator().manual_seed(7)) * 0.5).to(dtype)
+    ref = R.awq_gemm(x, R.awq_to_gptq_4bit(qw), sc, qz)
+    d = dev()
+    q2d = ops().awq_to_gptq_4bit(qw.to(d))
+    ws = torch.zeros(m, n, dtype=torch.float32, device=d)
+    out = ops().awq_gemm(x.to(d), q2d, qz.to(d), sc.to(d), 8, ws, True)
+    _check_gemm(out, ref, "awq_gemm llama3")
+
+
+def test_awq_gemm_strided_activations_and_errors():
+    dtype, m, k, n, group = torch.bfloat16, 9, 512, 128, 128
+    qw, qz, sc, _, _ = make_awq(k, n, group, dtype, seed=8)
+    xfull = torch.randn(m, 2 * k).to(dtype)
+    x = xfull[:, :k]
+    ref = R.awq_gemm(x, R.awq_to_gptq_4bit(qw), sc, qz)
+    d = dev()
+    q2d = ops().awq_to_gptq_4bit(qw.to(d))
+    out = ops().awq_gemm(xfull.to(d)[:, :k], q2d, qz.to(d), sc.to(d), 8, torch.empty(0), True)
+    _check_gemm(out, ref, "strided")
+    with pytest.raises(RuntimeError):   # dtype flag mismatch
+        ops().awq_gemm(x.to(d), q2d, qz.to(d), sc.to(d), 8, torch.empty(0), False)
+    with pytest.raises(RuntimeError):   # k not a multiple of 32 -> raise, never a silent false
+        ops().awq_gemm(x.to(d)[:, :500].contiguous(), q2d, qz.to(d), sc.to(d), 8, torch.empty(0), True)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m", [1, 16, 64, 77])
+@pytest.mark.parametrize("sym", [True, False])
+@pytest.mark.parametrize("act_order", [False, True])
+def test_gptq_gemm(dtype, m, sym, act_order):
+    k, n, group = 1024, 256, 128
+    qw, qz, sc = make_gptq(k, n, group, dtype, seed=9, sym=sym)
+    x = torch.randn(m, k, generator=torch.Generator().manual_seed(10)).to(dtype)
+    perm = torch.randperm(k, generator=torch.Generator().manual_seed(11)).to(torch.int32) if act_order \
+        else torch.empty(0, dtype=torch.int32)
+    shuf = R.gptq_shuffle(qw, perm)
+    ref = R.gptq_gemm(x, shuf, qz, sc, perm, group)
+    d = dev()
+    qd = qw.to(d).clone()
+    pd = perm.to(d) if act_order else perm
+    ops().gptq_shuffle(qd, pd, 4)
+    ws = torch.zeros(m, n, dtype=torch.float32, device=d)
+    pspace = torch.empty(m, k, dtype=torch.float16, device=d) if act_order else torch.empty(0)
+    out = ops().gptq_gemm(x.to(d), qd, qz.to(d), sc.to(d), pd, True, 4, group, pspace, ws,
+                          dtype == torch.bfloat16)
+    _check_gemm(out, ref, "gptq_gemm")
+
+
+def test_gptq_gemm_qwen2_72b_tp8_shapes():
+    """Qwen2-72B GPTQ per-rank shapes at TP=8, M = 64, symmetric zeros."""
+    dtype, m, group = torch.bfloat16, 64, 128
+    for k, n in [(8192, 1280), (1024, 8192), (8192, 7424), (3712, 8192)]:
+        qw, qz, sc = make_gptq(k, n, group, dtype, seed=12, sym=True)
+        x = (torch.randn(m, k, generator=torch.Generator().manual_seed(13)) * 0.5).to(dtype)
+        shuf = R.gptq_shuffle(qw, None)
+        ref = R.gptq_gemm(x, shuf, qz, sc, None, group)
+        d = dev()
+        qd = qw.to(d).clone()
+        ops().gptq_shuffle(qd, torch.empty(0, dtype=torch.int32), 4)
+        ws = torch.zeros(m, n, dtype=torch.float32, device=d)
+        out = ops().gptq_gemm(x.to(d), qd, qz.to(d), sc.to(d), torch.empty(0, dtype=torch.int32),
+                              True, 4, group, torch.empty(0), ws, True)
+        _check_gemm(out, ref, f"gptq_gemm {k}x{n}")

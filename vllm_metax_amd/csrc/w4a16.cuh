@@ -1,0 +1,93 @@
+// w4a16.cuh — pieces shared by the small-M and large-M w4a16 GEMM kernels.
+#pragma once
+#include "common.cuh"
+
+namespace mi355x {
+
+// AWQ nibble position of natural column j inside a packed word (inverse of the AWQ
+// packing order 0,2,4,6,1,3,5,7); the exllama k-row order uses the same table.
+__host__ __device__ constexpr int awq_shift(int j) { return (j >> 1) + 4 * (j & 1); }
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<bf16_t> {
+  static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+    bf16x2_t v = {static_cast<bf16_t>(lo), static_cast<bf16_t>(hi)};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+};
+template <>
+struct Mfma<f16_t> {
+  static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+    f16x2_t v = {static_cast<f16_t>(lo), static_cast<f16_t>(hi)};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+};
+
+// Dequantise one shuffled word (8 consecutive k of one column) into an MFMA B fragment:
+// value_j = fma(float(q_j), s, zs) with zs = -z*s, rounded to T, natural k order.
+template <typename T>
+__device__ __forceinline__ uint4 dequant_word(uint32_t w, float s, float zs) {
+  const uint32_t t0 = w & 0x0F0F0F0Fu;         // bytes: k0, k4, k1, k5
+  const uint32_t t1 = (w >> 4) & 0x0F0F0F0Fu;  // bytes: k2, k6, k3, k7
+  const float k0 = (float)((t0 >> 0) & 0xFFu);
+  const float k4 = (float)((t0 >> 8) & 0xFFu);
+  const float k1 = (float)((t0 >> 16) & 0xFFu);
+  const float k5 = (float)((t0 >> 24) & 0xFFu);
+  const float k2 = (float)((t1 >> 0) & 0xFFu);
+  const float k6 = (float)((t1 >> 8) & 0xFFu);
+  const float k3 = (float)((t1 >> 16) & 0xFFu);
+  const float k7 = (float)((t1 >> 24) & 0xFFu);
+  uint4 r;
+  r.x = Mfma<T>::pack(fmaf(k0, s, zs), fmaf(k1, s, zs));
+  r.y = Mfma<T>::pack(fmaf(k2, s, zs), fmaf(k3, s, zs));
+  r.z = Mfma<T>::pack(fmaf(k4, s, zs), fmaf(k5, s, zs));
+  r.w = Mfma<T>::pack(fmaf(k6, s, zs), fmaf(k7, s, zs));
+  return r;
+}
+
+enum ZeroMode { kZeroAwq = 0, kZeroGptq = 1 };
+
+// zero points of the 4 columns n .. n+3 (n % 4 == 0) of group row `zrow`
+template <int ZMODE>
+__device__ __forceinline__ void load_zeros4(const uint32_t* __restrict__ zrow, int n, float (&z)[4]) {
+  const uint32_t w = zrow[n >> 3];
+  const int base = n & 7;  // 0 or 4
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if constexpr (ZMODE == kZeroAwq) {
+      // natural column j sits at nibble awq_shift(j): {0,4,1,5} for base 0, {2,6,3,7} for base 4
+      const int sh = 4 * ((base >> 1) + (t >> 1) + 4 * (t & 1));
+      z[t] = (float)((w >> sh) & 0xFu);
+    } else {
+      z[t] = (float)(((w >> (4 * (base + t))) & 0xFu) + 1u);
+    }
+  }
+}
+
+
+struct GemmArgs {
+  void* c;
+  const void* a;
+  const uint32_t* qw;
+  const void* scales;
+  const uint32_t* qz;
+  float* ws;
+  int64_t ws_elems;
+  int m, n, k, group;
+  int64_t lda;
+  int zmode;
+  hipStream_t stream;
+};
+
+
+}  // namespace mi355x

@@ -1,0 +1,472 @@
+// w4a16.hip — int4 weight-only path for gfx950: AWQ->exllama repack, GPTQ shuffle,
+// AWQ dequantize, and the w4a16 dequant-GEMM on MFMA (v_mfma_f32_16x16x32_{bf16,f16}).
+//
+// Reference semantics restated:
+//   awq_to_gptq_4bit  csrc/quantization/awq/gemm_kernels.cu:127-184, 323-356
+//   awq_dequantize    csrc/quantization/awq/gemm_kernels.cu:96-125, 358-402
+//   awq_gemm          csrc/quantization/awq/gemm_kernels.cu:410-463 -> hgemm_gptq.h
+//                     :2165-2259; dequant w = T(fma(q, s, (-z)*s)) (hgemm_gptq.h:487-570,
+//                     :869-905), fp32 MMA accumulation, one rounding of C to T
+//   gptq_shuffle      csrc/quantization/gptq/q_gemm.cu:2321-2368, qdq_4.cuh:16-29,
+//                     q_gemm.cu:2145-2174 (make_sequential)
+//   gptq_gemm         csrc/quantization/gptq/q_gemm.cu:2373-2413 (zero = qzeros + 1, the
+//                     generic exllama semantics :247-250; equals the fast path's fixed 8 on
+//                     symmetric checkpoints), act-order gather perm_a :1770-1786
+//
+// Weight layout consumed by the GEMM (produced by awq_to_gptq_4bit / gptq_shuffle):
+//   words [K/8][N]; nibble p of word (kk, n) = W[8kk + {0,2,4,6,1,3,5,7}[p]][n].
+// One 32-bit word is exactly one lane's B fragment (8 consecutive k of one column) of
+// v_mfma_f32_16x16x32: lane (r = l>>4, c = l&15) loads the 4 words (kk = 4*step + r,
+// n = n0 + 4c .. 4c+3) with ONE 16-byte load, i.e. the fragments of 4 N-tiles whose
+// columns are interleaved (tile t owns columns n0 + 4c + t).  No LDS staging for B.
+//
+// Dequant (exact): (q - z) * s is representable in fp32 for 4-bit q, z and a T scale, so
+// T(fma(float(q), s, -z*s)) is the reference's value bit for bit.
+#include "w4a16.cuh"
+
+namespace mi355x {
+
+// ------------------------------------------------------------------ repack / shuffle
+
+// One thread per (k-block of 8 rows, word column): reads 8 AWQ words (rows 8kk..8kk+7 of
+// word column nw) and writes the 8 exllama words (kk, 8nw .. 8nw+7).
+__global__ void awq_to_gptq_4bit_kernel(uint32_t* __restrict__ out,
+                                        const uint32_t* __restrict__ in, int k, int n) {
+  const int n8 = n / 8;
+  const int k8 = (k + 7) / 8;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8 * k8) return;
+  const int nw = idx % n8;   // consecutive threads -> consecutive input words (coalesced)
+  const int kk = idx / n8;
+  uint32_t a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int row = kk * 8 + j;
+    a[j] = row < k ? in[(int64_t)row * n8 + nw] : 0u;
+  }
+  uint32_t o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // output column 8nw + i
+    uint32_t w = 0;
+    const int sh = 4 * awq_shift(i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {  // k row 8kk + j goes to nibble awq_shift(j) (= exllama order)
+      w |= ((a[j] >> sh) & 0xFu) << (4 * awq_shift(j));
+    }
+    o[i] = w;
+  }
+  uint32_t* dst = out + (int64_t)kk * n + nw * 8;
+  *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+  *reinterpret_cast<uint4*>(dst + 4) = make_uint4(o[4], o[5], o[6], o[7]);
+}
+
+// exllama nibble shuffle of one word: nibbles (k0..k7) -> (k0,k2,k4,k6,k1,k3,k5,k7)
+__device__ __forceinline__ uint32_t shuffle_4bit_word(uint32_t q) {
+  uint32_t r = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r |= ((q >> (8 * i)) & 0xFu) << (4 * i);
+    r |= ((q >> (8 * i + 4)) & 0xFu) << (4 * i + 16);
+  }
+  return r;
+}
+
+__global__ void gptq_shuffle_4bit_kernel(uint32_t* __restrict__ w, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) w[i] = shuffle_4bit_word(w[i]);
+}
+
+// 8-bit exllama shuffle (qdq_8.cuh: identity layout) — nothing to do per word.
+
+// make_sequential: new row r of the UNPACKED matrix = old row q_perm[r].
+__global__ void gptq_make_sequential_4bit_kernel(const uint32_t* __restrict__ w,
+                                                 uint32_t* __restrict__ w_new,
+                                                 const int* __restrict__ q_perm, int k8, int n) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row8 = blockIdx.y;
+  if (col >= n) return;
+  uint32_t dst = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int src_row = q_perm[row8 * 8 + i];
+    const uint32_t src = w[(int64_t)(src_row >> 3) * n + col];
+    dst |= ((src >> (4 * (src_row & 7))) & 0xFu) << (4 * i);
+  }
+  w_new[(int64_t)row8 * n + col] = dst;
+}
+
+__global__ void gptq_make_sequential_8bit_kernel(const uint32_t* __restrict__ w,
+                                                 uint32_t* __restrict__ w_new,
+                                                 const int* __restrict__ q_perm, int k4, int n) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row4 = blockIdx.y;
+  if (col >= n) return;
+  uint32_t dst = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int src_row = q_perm[row4 * 4 + i];
+    const uint32_t src = w[(int64_t)(src_row >> 2) * n + col];
+    dst |= ((src >> (8 * (src_row & 3))) & 0xFFu) << (8 * i);
+  }
+  w_new[(int64_t)row4 * n + col] = dst;
+}
+
+// ------------------------------------------------------------------- awq_dequantize
+// Original AWQ layout: qweight [K][N/8], qzeros [K/g][N/8] (both N-interleaved), scales
+// [K/g][N].  One thread per packed word -> 8 outputs (one 16-B store for 2-byte T).
+template <typename T>
+__global__ void awq_dequantize_kernel(T* __restrict__ out, const uint32_t* __restrict__ qw,
+                                      const T* __restrict__ scales,
+                                      const uint32_t* __restrict__ qz, int k, int n, int group) {
+  const int n8 = n / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)k * n8) return;
+  const int row = idx / n8;
+  const int nw = idx - (int64_t)row * n8;
+  const int g = row / group;
+  const uint32_t w = qw[idx];
+  const uint32_t z = qz[(int64_t)g * n8 + nw];
+  T o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int sh = 4 * awq_shift(j);
+    const float q = (float)((w >> sh) & 0xFu);
+    const float zz = (float)((z >> sh) & 0xFu);
+    const float s = to_f32(scales[(int64_t)g * n + nw * 8 + j]);
+    o[j] = from_f32<T>(fmaf(q, s, -zz * s));
+  }
+  T* dst = out + (int64_t)row * n + nw * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dst[j] = o[j];
+}
+
+// ------------------------------------------------------------------- act-order gather
+// out[m][kk] = in[m][perm[kk]]   (ref: perm_a, q_gemm.cu:1770-1786)
+template <typename T>
+__global__ void permute_cols_kernel(T* __restrict__ out, const T* __restrict__ in,
+                                    const int* __restrict__ perm, int m, int k, int64_t lda) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = blockIdx.y;
+  if (col < k) out[(int64_t)row * k + col] = in[(int64_t)row * lda + perm[col]];
+}
+
+// ------------------------------------------------------------------ small-M kernel
+// C[M<=64, N] tile 64 x 64 per workgroup; the 4 waves split the K range of the workgroup
+// (k-step = 32, interleaved) and are summed through LDS; blockIdx.y splits K across
+// workgroups (fp32 atomics into `acc_ws` when gridDim.y > 1).  HBM-bound regime: weights
+// are read exactly once, A (<= 64 rows, L2 resident) is read as MFMA-shaped fragments.
+constexpr int kSmBN = 64;
+constexpr int kSmThreads = 256;
+
+template <typename T, int MT, int ZMODE>
+__global__ __launch_bounds__(kSmThreads) void w4a16_gemm_small_m_kernel(
+    T* __restrict__ c, float* __restrict__ acc_ws, const T* __restrict__ a,
+    const uint32_t* __restrict__ qw, const T* __restrict__ scales,
+    const uint32_t* __restrict__ qz, int m, int n, int k, int group, int64_t lda,
+    int ksteps_per_split) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem);  // [2][MT*16][64] fp32
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lc = lane & 15;
+  const int lr = lane >> 4;
+  const int n0 = blockIdx.x * kSmBN;
+  const int ncol = n0 + 4 * lc;  // first of this lane's 4 columns
+
+  const int total_steps = k / 32;
+  const int step_begin = blockIdx.y * ksteps_per_split;
+  const int step_end = min(step_begin + ksteps_per_split, total_steps);
+
+  f32x4_t acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // A fragment row pointers (rows past M are clamped; their results are never stored)
+  const T* arow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    int r = i * 16 + lc;
+    r = r < m ? r : m - 1;
+    arow[i] = a + (int64_t)r * lda + 8 * lr;
+  }
+  const int n8 = n >> 3;
+
+  for (int s = step_begin + wave; s < step_end; s += 4) {
+    const int kbase = s * 32;
+    const int g = kbase / group;
+    const uint4 bw = *reinterpret_cast<const uint4*>(qw + (int64_t)(4 * s + lr) * n + ncol);
+    uint4 af[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(arow[i] + kbase);
+    // per-column scale / zero of this k-step's group
+    float sc[4], zp[4];
+    {
+      const T* sp = scales + (int64_t)g * n + ncol;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) sc[t] = to_f32(sp[t]);
+      load_zeros4<ZMODE>(qz + (int64_t)g * n8, ncol, zp);
+    }
+    const uint32_t words[4] = {bw.x, bw.y, bw.z, bw.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const uint4 bf = dequant_word<T>(words[t], sc[t], -zp[t] * sc[t]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][t] = Mfma<T>::run(af[i], bf, acc[i][t]);
+    }
+  }
+
+  // ---- sum the 4 waves (tree through LDS): 2,3 -> 0,1 ; 1 -> 0 -------------------
+  auto lds_store = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = i * 16 + 4 * lr + j;
+        *reinterpret_cast<float4*>(dst + row * 64 + 4 * lc) =
+            make_float4(acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]);
+      }
+    }
+  };
+  auto lds_add = [&](const float* src) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = i * 16 + 4 * lr + j;
+        const float4 v = *reinterpret_cast<const float4*>(src + row * 64 + 4 * lc);
+        acc[i][0][j] += v.x;
+        acc[i][1][j] += v.y;
+        acc[i][2][j] += v.z;
+        acc[i][3][j] += v.w;
+      }
+    }
+  };
+  constexpr int kSlab = MT * 16 * 64;
+  if (wave >= 2) lds_store(red + (wave - 2) * kSlab);
+  __syncthreads();
+  if (wave < 2) lds_add(red + wave * kSlab);
+  __syncthreads();
+  if (wave == 1) lds_store(red);
+  __syncthreads();
+  if (wave != 0) return;
+  lds_add(red);
+
+  // ---- epilogue: lane holds, for each (i, j), 4 consecutive columns ncol..ncol+3 ----
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = i * 16 + 4 * lr + j;
+      if (row >= m) continue;
+      if (gridDim.y == 1) {
+        const uint2 v = make_uint2(Mfma<T>::pack(acc[i][0][j], acc[i][1][j]),
+                                   Mfma<T>::pack(acc[i][2][j], acc[i][3][j]));
+        *reinterpret_cast<uint2*>(c + (int64_t)row * n + ncol) = v;
+      } else {
+        float* dst = acc_ws + (int64_t)row * n + ncol;
+        atomicAdd(dst + 0, acc[i][0][j]);
+        atomicAdd(dst + 1, acc[i][1][j]);
+        atomicAdd(dst + 2, acc[i][2][j]);
+        atomicAdd(dst + 3, acc[i][3][j]);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void f32_to_t_kernel(T* __restrict__ out, const float* __restrict__ in, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(in)[i];
+  T o[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
+  if constexpr (sizeof(T) == 2) {
+    reinterpret_cast<uint2*>(out)[i] = *reinterpret_cast<const uint2*>(o);
+  } else {
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+int w4a16_gemm_large_m_dispatch(const GemmArgs& g, int dtype);  // w4a16_large.hip
+
+template <typename T, int ZMODE>
+static int launch_small_m(const GemmArgs& g, int row0, int rows) {
+  const T* a = static_cast<const T*>(g.a) + (int64_t)row0 * g.lda;
+  T* c = static_cast<T*>(g.c) + (int64_t)row0 * g.n;
+  const int col_tiles = g.n / kSmBN;
+  const int total_steps = g.k / 32;
+  // split K across workgroups until ~2 workgroups per CU, keeping >= 8 k-steps per wave
+  int sk = 1;
+  const bool can_split = g.ws != nullptr && g.ws_elems >= (int64_t)rows * g.n;
+  if (can_split) {
+    while (col_tiles * sk < 512 && total_steps / (sk * 2) >= 32) sk *= 2;
+  }
+  const int steps_per_split = (total_steps + sk - 1) / sk;
+  sk = (total_steps + steps_per_split - 1) / steps_per_split;
+  float* ws = g.ws;
+  if (sk > 1) {
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)rows * g.n * sizeof(float), g.stream);
+    if (e != hipSuccess) {
+      set_error("w4a16_gemm: hipMemsetAsync: %s", hipGetErrorString(e));
+      return MI355X_ELAUNCH;
+    }
+  }
+  const int mt = (rows + 15) / 16;
+  dim3 grid(col_tiles, sk), block(kSmThreads);
+#define LAUNCH_SM(MTV)                                                                      \
+  hipLaunchKernelGGL((w4a16_gemm_small_m_kernel<T, MTV, ZMODE>), grid, block,               \
+                     (size_t)2 * MTV * 16 * 64 * sizeof(float), g.stream, c, ws, a, g.qw,    \
+                     static_cast<const T*>(g.scales), g.qz, rows, g.n, g.k, g.group, g.lda, \
+                     steps_per_split)
+  if (mt <= 1) LAUNCH_SM(1);
+  else if (mt <= 2) LAUNCH_SM(2);
+  else LAUNCH_SM(4);
+#undef LAUNCH_SM
+  int rc = check_launch("w4a16_gemm_small_m");
+  if (rc) return rc;
+  if (sk > 1) {
+    const int64_t n4 = (int64_t)rows * g.n / 4;
+    hipLaunchKernelGGL(f32_to_t_kernel<T>, dim3((n4 + 255) / 256), dim3(256), 0, g.stream, c, ws,
+                       n4);
+    rc = check_launch("w4a16_gemm_convert");
+  }
+  return rc;
+}
+
+template <typename T>
+static int run_gemm_t(const GemmArgs& g, int dtype) {
+  if (g.m >= 128) {
+    int rc = w4a16_gemm_large_m_dispatch(g, dtype);
+    if (rc != 1) return rc;  // 1 = shape not handled by the large-M kernel
+  }
+  for (int row0 = 0; row0 < g.m; row0 += 64) {
+    const int rows = (g.m - row0) < 64 ? (g.m - row0) : 64;
+    int rc = g.zmode == kZeroAwq ? launch_small_m<T, kZeroAwq>(g, row0, rows)
+                                 : launch_small_m<T, kZeroGptq>(g, row0, rows);
+    if (rc) return rc;
+  }
+  return MI355X_OK;
+}
+
+static int validate_gemm(const GemmArgs& g, const char* name) {
+  MI355X_REQUIRE(g.m >= 0 && g.n > 0 && g.k > 0 && g.group > 0, MI355X_EINVAL, "%s: bad sizes", name);
+  MI355X_REQUIRE(g.n % 64 == 0, MI355X_EUNSUPPORTED, "%s: n = %d must be a multiple of 64", name, g.n);
+  MI355X_REQUIRE(g.k % 32 == 0, MI355X_EUNSUPPORTED, "%s: k = %d must be a multiple of 32", name, g.k);
+  MI355X_REQUIRE(g.group % 32 == 0 && g.k % g.group == 0, MI355X_EUNSUPPORTED,
+                 "%s: group_size %d must be a multiple of 32 that divides k", name, g.group);
+  MI355X_REQUIRE(g.lda % 8 == 0 && (reinterpret_cast<uintptr_t>(g.a) & 15) == 0, MI355X_EUNSUPPORTED,
+                 "%s: activations must be 16-byte aligned with lda %% 8 == 0", name);
+  if (g.m == 0) return MI355X_OK;
+  MI355X_REQUIRE(g.c && g.a && g.qw && g.scales && g.qz, MI355X_EINVAL, "%s: null pointer", name);
+  return MI355X_OK;
+}
+
+}  // namespace mi355x
+
+using namespace mi355x;
+
+extern "C" {
+
+int mi355x_awq_to_gptq_4bit(uint32_t* out, const uint32_t* qweight, int k, int n,
+                            mi355x_stream stream) {
+  MI355X_REQUIRE(k > 0 && n > 0 && n % 8 == 0, MI355X_EINVAL,
+                 "awq_to_gptq_4bit: bad sizes k=%d n=%d", k, n);
+  MI355X_REQUIRE(out && qweight, MI355X_EINVAL, "awq_to_gptq_4bit: null pointer");
+  MI355X_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, MI355X_EINVAL,
+                 "awq_to_gptq_4bit: out must be 16-byte aligned");
+  const int total = (n / 8) * ((k + 7) / 8);
+  hipLaunchKernelGGL(awq_to_gptq_4bit_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), out, qweight, k, n);
+  return check_launch("awq_to_gptq_4bit");
+}
+
+int mi355x_awq_dequantize(void* out, const uint32_t* qweight, const void* scales,
+                          const uint32_t* qzeros, int k, int n, int group_size,
+                          int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(k > 0 && n > 0 && n % 8 == 0 && group_size > 0, MI355X_EINVAL,
+                 "awq_dequantize: bad sizes");
+  MI355X_REQUIRE(out && qweight && scales && qzeros, MI355X_EINVAL, "awq_dequantize: null pointer");
+  return MI355X_DISPATCH_HALF(dtype, [&] {
+    const int64_t total = (int64_t)k * (n / 8);
+    hipLaunchKernelGGL(awq_dequantize_kernel<scalar_t>, dim3((total + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<scalar_t*>(out), qweight,
+                       static_cast<const scalar_t*>(scales), qzeros, k, n, group_size);
+    return check_launch("awq_dequantize");
+  });
+}
+
+int mi355x_gptq_shuffle(uint32_t* q_weight, const int* q_perm, uint32_t* scratch, int k,
+                        int n, int bit, mi355x_stream stream) {
+  MI355X_REQUIRE(bit == 4 || bit == 8, MI355X_EUNSUPPORTED,
+                 "gptq_shuffle: only 4- and 8-bit weights are supported (bit=%d)", bit);
+  MI355X_REQUIRE(k > 0 && n > 0 && k % 32 == 0, MI355X_EINVAL, "gptq_shuffle: bad sizes");
+  MI355X_REQUIRE(q_weight, MI355X_EINVAL, "gptq_shuffle: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rows = k / 32 * bit;  // packed rows
+  if (q_perm) {
+    MI355X_REQUIRE(scratch, MI355X_EINVAL, "gptq_shuffle: q_perm given but no scratch buffer");
+    dim3 grid((n + 255) / 256, rows), block(256);
+    if (bit == 4)
+      hipLaunchKernelGGL(gptq_make_sequential_4bit_kernel, grid, block, 0, s, q_weight, scratch,
+                         q_perm, rows, n);
+    else
+      hipLaunchKernelGGL(gptq_make_sequential_8bit_kernel, grid, block, 0, s, q_weight, scratch,
+                         q_perm, rows, n);
+    int rc = check_launch("gptq_make_sequential");
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(q_weight, scratch, (size_t)rows * n * sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) {
+      set_error("gptq_shuffle: hipMemcpyAsync: %s", hipGetErrorString(e));
+      return MI355X_ELAUNCH;
+    }
+  }
+  if (bit == 4) {
+    const int64_t total = (int64_t)rows * n;
+    hipLaunchKernelGGL(gptq_shuffle_4bit_kernel, dim3((total + 255) / 256), dim3(256), 0, s,
+                       q_weight, total);
+    return check_launch("gptq_shuffle");
+  }
+  return MI355X_OK;
+}
+
+int mi355x_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* scales,
+                    const uint32_t* qzeros, float* workspace, int64_t workspace_elems,
+                    int m, int n, int k, int group_size, int64_t lda, int dtype,
+                    mi355x_stream stream) {
+  GemmArgs g{c, a, qweight, scales, qzeros, workspace, workspace_elems, m, n, k, group_size,
+             lda, kZeroAwq, static_cast<hipStream_t>(stream)};
+  int rc = validate_gemm(g, "awq_gemm");
+  if (rc || m == 0) return rc;
+  return MI355X_DISPATCH_HALF(dtype, [&] { return run_gemm_t<scalar_t>(g, dtype); });
+}
+
+int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,
+                     const uint32_t* qzeros, const void* scales, const int* g_idx,
+                     void* perm_space, float* workspace, int64_t workspace_elems, int m,
+                     int n, int k, int bit, int group_size, int dtype,
+                     mi355x_stream stream) {
+  MI355X_REQUIRE(bit == 4, MI355X_EUNSUPPORTED,
+                 "gptq_gemm: only 4-bit weights are implemented (bit=%d)", bit);
+  GemmArgs g{c, a, qweight, scales, qzeros, workspace, workspace_elems, m, n, k, group_size,
+             k, kZeroGptq, static_cast<hipStream_t>(stream)};
+  int rc = validate_gemm(g, "gptq_gemm");
+  if (rc || m == 0) return rc;
+  if (g_idx) {
+    MI355X_REQUIRE(perm_space, MI355X_EINVAL, "gptq_gemm: act-order needs perm_space");
+    rc = MI355X_DISPATCH_HALF(dtype, [&] {
+      hipLaunchKernelGGL(permute_cols_kernel<scalar_t>, dim3((k + 255) / 256, m), dim3(256), 0,
+                         g.stream, static_cast<scalar_t*>(perm_space),
+                         static_cast<const scalar_t*>(a), g_idx, m, k, (int64_t)k);
+      return check_launch("gptq_gemm_permute");
+    });
+    if (rc) return rc;
+    g.a = perm_space;
+  }
+  return MI355X_DISPATCH_HALF(dtype, [&] { return run_gemm_t<scalar_t>(g, dtype); });
+}
+
+}  // extern "C"
