@@ -253,13 +253,16 @@ int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,
  * out[M,N] (bf16/f16) = (a_scales . a[M,K] e4m3fn row-major) x
  *                       (b_scales . b[K,N] e4m3fn COLUMN-major, ldb = b.stride(1))
  *                       (+ bias[N]).  a_scales: 1 or M floats; b_scales: 1 or N.
+ * `workspace` (float, >= m*n, may be NULL) lets the small-M kernel split K across
+ * workgroups; it is zero-filled by the call.
  * New capability behind the reference schema cutlass_scaled_mm
  * (csrc/torch_bindings.cpp:251-256; csrc/quantization/cutlass_w8a8/
  *  scaled_mm_entry.cu:34-39,84-140), which the reference only implements for int8. */
 int mi355x_scaled_mm_fp8(void* out, const void* a, const void* b, const float* a_scales,
                          int a_scales_numel, const float* b_scales, int b_scales_numel,
-                         const void* bias, int m, int n, int k, int64_t lda, int64_t ldb,
-                         int64_t ldc, int out_dtype, mi355x_stream stream);
+                         const void* bias, float* workspace, int64_t workspace_elems, int m,
+                         int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype,
+                         mi355x_stream stream);
 
 #ifdef __cplusplus
 }

@@ -339,5 +339,6 @@ def test_silu_and_mul(dtype, d_, tokens):
     if dtype == torch.float32:
         assert_close_rel(out, ref, 1e-6, "silu_and_mul")
     else:
-        # __expf vs torch.exp can differ by an fp32 ulp -> rare 1-ulp flips after rounding
-        assert_mostly_exact(out, ref, 1, 2e-3, "silu_and_mul")
+        # expf vs torch.exp can differ by an fp32 ulp -> rare 1-ulp flips of T(silu(x)),
+        # which the following T*T product can turn into 2 ulp of the output
+        assert_mostly_exact(out, ref, 2, 2e-3, "silu_and_mul")

@@ -1,0 +1,76 @@
+"""GPU parity: FP8 (e4m3fn) scaled GEMM behind the cutlass_scaled_mm schema.
+
+Oracle: oracle/ref_ops.scaled_mm_fp8, after the reference's test-side definition
+tests/kernels/utils.py:1231-1270 (the reference itself has no fp8 implementation,
+scaled_mm_entry.cu:22-24).  Inputs as in tests/kernels/quantization/
+test_cutlass_scaled_mm.py:68-100 (fp8 of scaled randn, per-tensor / per-token /
+per-channel scales, optional bias); tolerance: one output ulp + 2e-4 * max|ref| (the
+reference test uses rtol 5e-1 / atol 1.5e-1; north_star asks <= 1e-3 rel).
+"""
+import pytest
+import torch
+
+from tests.util import assert_gemm_close, dev
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_ops as R  # noqa: E402
+
+FP8 = torch.float8_e4m3fn
+
+
+def ops():
+    from vllm_metax_amd import _custom_ops
+    return _custom_ops
+
+
+def _mk(m, n, k, per_token, per_channel, bias, out_dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn(m, k, generator=g) * 2).clamp(-448, 448).to(FP8)
+    b = (torch.randn(n, k, generator=g) * 2).clamp(-448, 448).to(FP8).t()   # [K, N] column-major
+    a_s = torch.rand(m if per_token else 1, 1, generator=g) * 9e-3 + 1e-3
+    b_s = torch.rand(1, n if per_channel else 1, generator=g) * 9e-3 + 1e-3
+    bi = (torch.rand(n, generator=g) * 2 - 1).to(out_dtype) if bias else None
+    return a, b, a_s, b_s, bi
+
+
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,n,k", [(1, 256, 128), (16, 128, 512), (33, 496, 1024), (64, 1280, 8192),
+                                   (100, 256, 256), (512, 512, 512), (300, 1000, 1024)])
+@pytest.mark.parametrize("per_token,per_channel", [(False, False), (True, True), (True, False), (False, True)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_scaled_mm_fp8(out_dtype, m, n, k, per_token, per_channel, bias):
+    a, b, a_s, b_s, bi = _mk(m, n, k, per_token, per_channel, bias, out_dtype)
+    ref = R.scaled_mm_fp8(a, b, a_s, b_s, out_dtype, bi)
+    d = dev()
+    bd = b.t().contiguous().to(d).t()          # keep it column-major on the device
+    out = torch.empty(m, n, dtype=out_dtype, device=d)
+    ops().cutlass_scaled_mm(out, a.to(d), bd, a_s.to(d), b_s.to(d), bi.to(d) if bias else None)
+    assert_gemm_close(out, ref, f"scaled_mm_fp8 {m}x{n}x{k}")
+
+
+def test_scaled_mm_fp8_llama70b_tp8_shapes():
+    """Llama-3-70B FP8 per-rank shapes at TP=8: decode M=64 and a prefill chunk."""
+    for m in (64, 2048):
+        for k, n in [(8192, 1280), (1024, 8192), (8192, 7168), (3584, 8192)]:
+            a, b, a_s, b_s, _ = _mk(m, n, k, True, True, False, torch.bfloat16, seed=3)
+            ref = R.scaled_mm_fp8(a, b, a_s, b_s, torch.bfloat16)
+            d = dev()
+            bd = b.t().contiguous().to(d).t()
+            out = torch.empty(m, n, dtype=torch.bfloat16, device=d)
+            ops().cutlass_scaled_mm(out, a.to(d), bd, a_s.to(d), b_s.to(d), None)
+            assert_gemm_close(out, ref, f"70B shape {m}x{n}x{k}")
+
+
+def test_scaled_mm_fp8_errors():
+    d = dev()
+    a = torch.zeros(16, 128, dtype=FP8, device=d)
+    b = torch.zeros(128, 64, dtype=FP8, device=d)           # row-major b: rejected
+    out = torch.empty(16, 64, dtype=torch.bfloat16, device=d)
+    s = torch.ones(1, dtype=torch.float32, device=d)
+    with pytest.raises(RuntimeError):
+        ops().cutlass_scaled_mm(out, a, b, s, s, None)
+    bi = torch.zeros(64, 128, dtype=torch.int8, device=d).t()
+    with pytest.raises(RuntimeError):                        # int8 operands: out of scope
+        ops().cutlass_scaled_mm(out, a.view(torch.int8), bi, s, s, None)
+    assert ops().cutlass_scaled_mm_supports_fp8(90) is True

@@ -79,3 +79,27 @@ def make_kv_cache_x(num_blocks, block_size, num_kv_heads, head_size, dtype, seed
     kc = (torch.rand(num_blocks, num_kv_heads, head_size // x, block_size, x, generator=g) * 2 - 1) * scale
     vc = (torch.rand(num_blocks, num_kv_heads, head_size, block_size, generator=g) * 2 - 1) * scale
     return kc.to(dtype), vc.to(dtype)
+
+
+def assert_gemm_close(got, ref, what="", rel=2e-4, max_frac=0.05):
+    """GEMM-type outputs rounded once to a 16-bit type.  The reference value and ours are
+    roundings of two fp32 sums that differ only in accumulation order, so:
+      * every element is within ONE ulp of the output type (a rounding flip) plus
+        rel * max|ref| (accumulation-order noise; matters only where the sum cancels), which
+        also implies the north_star bound max|err| <= 1e-3 * max|ref| before output rounding;
+      * at most `max_frac` of the elements differ at all."""
+    g, r = got.detach().cpu(), ref.detach().cpu()
+    assert g.shape == r.shape and g.dtype == r.dtype, f"{what}: {g.shape}{g.dtype} vs {r.shape}{r.dtype}"
+    gf, rf = g.double(), r.double()
+    assert torch.isfinite(gf).all(), f"{what}: non-finite values"
+    eps = {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7, torch.float32: 2.0 ** -23}[g.dtype]
+    mag = torch.maximum(gf.abs(), rf.abs())
+    ulp = torch.pow(2.0, torch.floor(torch.log2(torch.clamp(mag, min=1e-30)))) * eps
+    bound = ulp + rel * rf.abs().max()
+    err = (gf - rf).abs()
+    bad = err > bound
+    assert not bad.any(), (f"{what}: {int(bad.sum())} elements beyond 1 ulp + {rel:g}*max|ref|; "
+                           f"worst err {err.max().item():.3e} (max|ref| {rf.abs().max().item():.3e})")
+    frac = (g.view(torch.int16 if g.element_size() == 2 else torch.int32)
+            != r.view(torch.int16 if r.element_size() == 2 else torch.int32)).double().mean().item()
+    assert frac <= max_frac, f"{what}: {frac:.3%} of elements differ (> {max_frac:.1%})"

@@ -539,8 +539,10 @@ def cutlass_scaled_mm(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
         raise RuntimeError("cutlass_scaled_mm: scales must be contiguous")
     if bias is not None and (bias.numel() != n or not bias.is_contiguous() or bias.dtype != out.dtype):
         raise RuntimeError("cutlass_scaled_mm: bad bias")
+    # small-M (decode) shapes split K across workgroups through an fp32 workspace
+    ws = torch.empty((m, n), dtype=torch.float32, device=a.device) if m <= 64 else None
     rc = _abi.load().mi355x_scaled_mm_fp8(
         _ptr(out), _ptr(a), _ptr(b), _ptr(a_scales), a_scales.numel(), _ptr(b_scales),
-        b_scales.numel(), _ptr(bias), m, n, k, a.stride(0), b.stride(1), out.stride(0),
-        _dt(out), _stream())
+        b_scales.numel(), _ptr(bias), _ptr(ws), ws.numel() if ws is not None else 0, m, n, k,
+        a.stride(0), b.stride(1), out.stride(0), _dt(out), _stream())
     _abi.check(rc, "cutlass_scaled_mm")

@@ -111,7 +111,7 @@ def build_torch_ops(force: bool = False, verbose: bool = True) -> Path:
     cmd = [
         "g++", "-O2", "-fPIC", "-shared", "-std=c++17",
         f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
-        "-DTORCH_EXTENSION_NAME=_C", f"-I{INCLUDE}", f"-I{rocm}/include", *inc,
+        "-DTORCH_EXTENSION_NAME=_C", f"-I{INCLUDE}", f"-I{rocm}/include", "-I/usr/include/python3.10", *inc,
         str(src), "-o", str(TORCH_OPS_LIB),
         f"-L{PKG_DIR}", "-lmi355x_hotpath", f"-L{torch_lib}", "-ltorch", "-ltorch_cpu",
         "-lc10", "-ltorch_hip", "-lc10_hip", f"-L{rocm}/lib", "-lamdhip64",

@@ -11,7 +11,7 @@ namespace mi355x {
 template <typename T>
 __device__ __forceinline__ T silu_t(T x) {
   const float xf = to_f32(x);
-  return from_f32<T>(xf / (1.0f + __expf(-xf)));
+  return from_f32<T>(xf / (1.0f + expf(-xf)));
 }
 
 template <typename T, bool VEC>

@@ -55,16 +55,21 @@ __device__ __forceinline__ float bf16hi_to_f32(uint32_t packed) {
 }
 
 // `a op b` evaluated the way c10 scalar types do it: in float, then rounded to T.
+// Contraction is switched off here: hipcc otherwise narrows these to native f16 ops and
+// then fuses T(a*b) - T(c*d) into one fma, dropping the reference's intermediate rounding.
 template <typename T>
 __device__ __forceinline__ T mul_t(T a, T b) {
+#pragma clang fp contract(off)
   return from_f32<T>(to_f32(a) * to_f32(b));
 }
 template <typename T>
 __device__ __forceinline__ T add_t(T a, T b) {
+#pragma clang fp contract(off)
   return from_f32<T>(to_f32(a) + to_f32(b));
 }
 template <typename T>
 __device__ __forceinline__ T sub_t(T a, T b) {
+#pragma clang fp contract(off)
   return from_f32<T>(to_f32(a) - to_f32(b));
 }
 

@@ -3,4 +3,3 @@
 using namespace mi355x;
 #define STUB(name, ...) extern "C" int name(__VA_ARGS__) { set_error(#name ": not implemented yet"); return MI355X_EUNSUPPORTED; }
 STUB(mi355x_paged_prefill_attention, void*, const void*, const void*, const void*, int, int, int, int, int, float, const int*, const int*, const int*, int, int, int64_t, int64_t, int64_t, int64_t, int, mi355x_stream)
-STUB(mi355x_scaled_mm_fp8, void*, const void*, const void*, const float*, int, const float*, int, const void*, int, int, int, int64_t, int64_t, int64_t, int, mi355x_stream)
