@@ -1,0 +1,361 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X hot path (contract: see the task brief).
+
+Workload (BASELINE.json metric "output tokens/sec + p50 TTFT, Llama-3-8B AWQ-int4 TP=1"):
+one STEP = one whole serving job on synthetic data — 64 prompts x 1024 tokens prefilled in
+chunks of 8 sequences (8192 tokens, the chunked-prefill budget), then greedy decode to 128
+output tokens per sequence (the first comes from the prefill, 127 decode steps follow, context
+1024..1150).  Weights are synthetic tensors of the Llama-3-8B AWQ (w4a16, g=128) architecture,
+KV cache block_size 16 in the reference's x-split paged layout.  Every hot-path op runs
+through the C-ABI HIP library; decode steps are replayed from a HIP graph.
+
+    value = K * 64 * 128 output tokens / wall time of K jobs (inputs resident in HBM).
+
+`--gpus N` (launched by torch.distributed.run, one rank per GPU) shards the SAME job with
+tensor parallelism TP=N (heads / FFN sharded, RCCL all-reduce after o_proj and down_proj,
+all-gather of the vocab-parallel logits): total work is fixed -> "scaling": "strong".
+
+Extra objects on the JSON line: "roofline" (dominant kernel, timed live with HIP events on
+the launch stream inside the timed region), "roofline_other" (the other hot kernels),
+"cpu_baseline" (oracle/cpu_port.c — the C restatement — timed on the host cores, rank 0,
+N=1 only), "ttft_p50_ms".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--quant", default="awq", choices=["awq", "gptq", "fp8", "none"])
+    ap.add_argument("--model", default="llama-3-8b", choices=["llama-3-8b", "tiny"])
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--input-len", type=int, default=1024)
+    ap.add_argument("--output-len", type=int, default=128)
+    ap.add_argument("--chunk-seqs", type=int, default=8)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--kernel-stats", action="store_true",
+                    help="print the per-kernel event timings table to stderr")
+    return ap.parse_args()
+
+
+class EventTimer:
+    """HIP-event timing of individual launches on torch's current stream (the stream every
+    C-ABI call is launched on).  Keeps (name, flops, bytes, start, stop) tuples."""
+
+    def __init__(self):
+        self.records = []
+        self.enabled = False
+
+    def time(self, name, flops, nbytes, fn):
+        if not self.enabled:
+            return fn()
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = fn()
+        b.record()
+        self.records.append((name, flops, nbytes, a, b))
+        return out
+
+    def summary(self):
+        agg = {}
+        for name, flops, nbytes, a, b in self.records:
+            ms = a.elapsed_time(b)
+            d = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += ms
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return agg
+
+
+def instrument(model, timer: EventTimer):
+    """Wrap the hot ops of the harness so that each launch is bracketed by HIP events."""
+    from vllm_metax_amd import _custom_ops as ops
+    from vllm_metax_amd import harness
+
+    orig_call = harness.QLinear.__call__
+
+    def timed_linear(self, x):
+        m = x.shape[0]
+        flops = 2.0 * m * self.n * self.k
+        nbytes = self.weight_bytes() + 2.0 * m * self.k + 2.0 * m * self.n
+        name = f"{self.quant}_gemm_{'large' if m >= 128 else 'small'}_m"
+        return timer.time(name, flops, nbytes, lambda: orig_call(self, x))
+
+    harness.QLinear.__call__ = timed_linear
+
+    def wrap(opname, cost):
+        fn = getattr(ops, opname)
+
+        def w(*a, **k):
+            flops, nbytes = cost(*a, **k)
+            return timer.time(opname, flops, nbytes, lambda: fn(*a, **k))
+        setattr(ops, opname, w)
+
+    def cost_prefill(out, q, kc, vc, kvh, scale, bt, sl, cu, max_q, bs):
+        T, H, D = q.shape
+        n = sl.numel()
+        ql = T // n
+        L = int(model.cfg_ctx_for_cost) + ql
+        flops = 4.0 * n * ql * (L - ql / 2.0) * H * D
+        nbytes = 2.0 * T * H * D * 2 + n * L * kvh * D * 2 * 2
+        return flops, nbytes
+
+    def cost_decode(out, es, ml, tmp, q, kc, vc, kvh, scale, bt, sl, bs, max_len, *a, **k):
+        S, H, D = q.shape
+        mean_len = model.mean_decode_len_for_cost
+        nbytes = S * mean_len * kvh * D * 2 * 2 + 2.0 * S * H * D * 2
+        return 4.0 * S * mean_len * H * D, nbytes
+
+    def cost_rows(n_reads, n_writes):
+        def c(*a, **k):
+            t = a[0]
+            return 0.0, float(t.numel() * t.element_size() * (n_reads + n_writes))
+        return c
+
+    wrap("paged_prefill_attention", cost_prefill)
+    wrap("paged_attention_v2", cost_decode)
+    wrap("fused_add_rms_norm", cost_rows(3, 2))
+    wrap("rms_norm", cost_rows(1, 1))
+    wrap("silu_and_mul", cost_rows(2, 1))
+    wrap("rotary_embedding", lambda pos, q, k, *a: (0.0, 2.0 * (q.numel() + (k.numel() if k is not None else 0)) * 2))
+    wrap("reshape_and_cache", lambda key, value, *a, **k: (0.0, 4.0 * key.numel() * 2))
+
+
+def run_job(model, tokens, args, timer=None, ttft=None):
+    """One whole job.  Returns nothing; `ttft` (list) receives per-sequence first-token events."""
+    B, Lin, Lout = args.batch, args.input_len, args.output_len
+    first = torch.empty(B, dtype=torch.int64, device=model.device)
+    for c0 in range(0, B, args.chunk_seqs):
+        ids = list(range(c0, min(c0 + args.chunk_seqs, B)))
+        model.cfg_ctx_for_cost = 0
+        nxt = model.prefill(tokens[ids[0]:ids[-1] + 1], ids, 0)
+        first[ids[0]:ids[-1] + 1] = nxt
+        if ttft is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            ttft.append((len(ids), ev))
+    model.d_tokens.copy_(first)
+    model.set_decode_lengths(torch.full((B,), Lin, device=model.device))
+    for _ in range(Lout - 1):
+        model.decode_step(use_graph=not args.no_graph)
+
+
+def cpu_baseline(args, cfg):
+    """oracle/cpu_port.c on the host cores: one decoder layer at the decode shape + lm_head,
+    extrapolated to the job (see the 'sample' string)."""
+    from oracle import cpu_port as C
+    from oracle import ref_ops as R
+    import numpy as np
+    torch.manual_seed(0)
+    B, ctx = args.batch, args.input_len + args.output_len // 2
+    h, d, H, KVH, ffn, g = cfg.hidden, cfg.head_dim, cfg.heads, cfg.kv_heads, cfg.ffn, cfg.group_size
+    bf = torch.bfloat16
+
+    def mk(k, n):
+        qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (k // 8, n), dtype=torch.int32)
+        qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (k // g, n // 8), dtype=torch.int32)
+        sc = (torch.rand(k // g, n) * 4e-3 + 1e-3).to(bf)
+        return qw, qz, sc
+    W = {"qkv": mk(h, (H + 2 * KVH) * d), "o": mk(H * d, h), "gu": mk(h, 2 * ffn), "down": mk(ffn, h)}
+    nblk = (ctx + 15) // 16
+    kc = (torch.rand(B * nblk, KVH, d // 8, 16, 8) * 0.2 - 0.1).to(bf)
+    vc = (torch.rand(B * nblk, KVH, d, 16) * 0.2 - 0.1).to(bf)
+    bt = torch.randperm(B * nblk).to(torch.int32).reshape(B, nblk)
+    sl = torch.full((B,), ctx, dtype=torch.int32)
+    x = (torch.randn(B, h) * 0.5).to(bf)
+    res = x.clone()
+    ln = torch.ones(h, dtype=bf)
+    cache = torch.randn(ctx + 1, d).to(bf)
+    pos = torch.full((B,), ctx - 1, dtype=torch.int64)
+    slots = (bt[:, (ctx - 1) // 16].long() * 16 + (ctx - 1) % 16)
+    lm = (torch.randn(h, cfg.vocab) * 0.02).to(bf)
+
+    def layer():
+        C.fused_add_rms_norm(x, res, ln, cfg.eps)
+        qkv = C.w4a16_gemm(x, *[W["qkv"][i] for i in (0, 2, 1)], 0, g)
+        q, k, v = qkv[:, :H * d], qkv[:, H * d:(H + KVH) * d], qkv[:, (H + KVH) * d:]
+        C.rotary_neox(pos, q, k, cache, H, KVH, d)
+        C.reshape_and_cache(k.reshape(B, KVH, d), v.reshape(B, KVH, d).contiguous(), kc, vc, slots)
+        a = C.paged_attention_v1(q.reshape(B, H, d), kc, vc, KVH, d ** -0.5, bt, sl)
+        o = C.w4a16_gemm(a.reshape(B, H * d), *[W["o"][i] for i in (0, 2, 1)], 0, g)
+        C.fused_add_rms_norm(o, res, ln, cfg.eps)
+        gu = C.w4a16_gemm(o, *[W["gu"][i] for i in (0, 2, 1)], 0, g)
+        act = C.silu_and_mul(gu)
+        return C.w4a16_gemm(act, *[W["down"][i] for i in (0, 2, 1)], 0, g)
+
+    layer()  # warm (page in, thread pool)
+    t0 = time.perf_counter(); layer(); t_layer = time.perf_counter() - t0
+    t0 = time.perf_counter(); C.gemm_bf16(x, lm); t_head = time.perf_counter() - t0
+    # job estimate: every token position (prefill + decode) pays the per-token layer cost of
+    # the M=64 sample; prefill attention is NOT counted (under-estimates CPU time).
+    positions = args.batch * (args.input_len + args.output_len - 1)
+    steps_equiv = positions / float(B)
+    t_job = cfg.layers * t_layer * steps_equiv + t_head * (args.output_len)
+    return {
+        "value": round(args.batch * args.output_len / t_job, 3),
+        "unit": "output tokens/s",
+        "cores": C.num_threads(),
+        "kind": "port",
+        "sample": (f"oracle/cpu_port.c: 1 of {cfg.layers} decoder layers at batch {B}, ctx {ctx} "
+                   f"({t_layer:.2f} s) + lm_head ({t_head:.2f} s); job time extrapolated as "
+                   f"layers x per-64-token layer cost x {steps_equiv:.0f} token groups + {args.output_len} "
+                   f"lm_head calls, prefill attention not counted"),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        group = torch.distributed.group.WORLD
+
+    from vllm_metax_amd import harness
+    cfg = harness.ModelConfig.llama3_8b(args.quant, tp=world) if args.model == "llama-3-8b" \
+        else harness.ModelConfig.tiny(args.quant)
+    cfg.tp = world
+    max_len = args.input_len + args.output_len
+    model = harness.HotPathModel(cfg, args.batch, max_len, device=f"cuda:{local_rank}", seed=0,
+                                 tp_group=group)
+    model.setup_decode(args.batch, args.input_len, max_len)
+    model.cfg_ctx_for_cost = 0
+    model.mean_decode_len_for_cost = args.input_len + (args.output_len - 1) / 2.0 + 1
+    gen = torch.Generator(device=model.device).manual_seed(0)
+    tokens = torch.randint(0, cfg.vocab, (args.batch, args.input_len), device=model.device, generator=gen)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # every hot op is wrapped so that a launch CAN be bracketed by HIP events; the timer is
+    # off during warm-up / graph capture and on inside the timed region, where it sees the
+    # eagerly launched kernels (all of prefill); graph-replayed decode launches are timed
+    # afterwards by a few eager decode steps on the same stream.
+    timer = EventTimer()
+    instrument(model, timer)
+    for _ in range(max(args.warmup, 1)):   # at least one: builds the decode graph
+        run_job(model, tokens, args)
+    barrier()
+    timer.enabled = True
+
+    # ---- timed region: exactly K jobs -------------------------------------------------
+    ttft_events = []
+    start_ev = []
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        s = torch.cuda.Event(enable_timing=True)
+        s.record()
+        tt = []
+        run_job(model, tokens, args, ttft=tt)
+        start_ev.append(s)
+        ttft_events.append(tt)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=model.device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+
+    ttfts = []
+    for s, tt in zip(start_ev, ttft_events):
+        for n, ev in tt:
+            ttfts += [s.elapsed_time(ev)] * n
+    ttft_p50 = statistics.median(ttfts) if ttfts else None
+
+    # ---- decode kernels: 8 eager decode steps at the mean decode context, bracketed ----------
+    mid = args.input_len + (args.output_len - 1) // 2
+    model.set_decode_lengths(torch.full((args.batch,), mid, device=model.device))
+    model.mean_decode_len_for_cost = mid + 1 + 3.5
+    for _ in range(8):
+        model.decode_step(use_graph=False)
+    torch.cuda.synchronize()
+    timer.enabled = False
+    agg = timer.summary()
+
+    def roof(name, d):
+        avg_ms = d["ms"] / d["launches"]
+        if d["flops"] > 0 and name.endswith("large_m") or name == "paged_prefill_attention":
+            ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+            return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2),
+                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
+                    "total_ms": round(d["ms"], 2)}
+        ach = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
+                "total_ms": round(d["ms"], 2)}
+
+    roofs = sorted((roof(n, d) for n, d in agg.items()), key=lambda r: -r["total_ms"])
+    if args.kernel_stats and rank == 0:
+        for r in roofs:
+            print(json.dumps(r), file=sys.stderr)
+
+    if rank != 0:
+        return
+    out_tokens = args.steps * args.batch * args.output_len
+    result = {
+        "metric": "output tokens/sec (Llama-3-8B AWQ-int4, batch 64, 1024-in/128-out) + p50 TTFT",
+        "value": round(out_tokens / elapsed, 2),
+        "unit": "output tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "bf16" if args.quant != "fp8" else "fp8",
+        "data": "synthetic",
+        "config": {"workload": f"{cfg.name}-{args.quant} w4a16 g128: prefill {args.batch}x{args.input_len} "
+                               f"in chunks of {args.chunk_seqs} seqs + {args.output_len - 1} graph-replayed "
+                               f"decode steps (1 step = 1 whole job)",
+                   "batch": args.batch, "input_len": args.input_len, "output_len": args.output_len,
+                   "parallelism": f"tp{world}", "kv_block_size": 16},
+        "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
+        "roofline": roofs[0] if roofs else None,
+        "roofline_other": roofs[1:],
+    }
+    if world == 1 and not args.skip_cpu:
+        try:
+            result["cpu_baseline"] = cpu_baseline(args, cfg)
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            result["cpu_baseline"] = {"value": None, "unit": "output tokens/s", "cores": 0,
+                                      "kind": "port", "sample": f"failed: {e!r}"}
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

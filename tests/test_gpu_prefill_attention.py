@@ -1,0 +1,103 @@
+"""GPU parity: paged prefill / chunked prefill attention against the CPU oracle.
+
+Batch specs after the reference's backend-level test tests/v1/attention/
+test_attention_backends.py:47-70 (prefill and mixed batches, query_len << / == seq_len) and
+tests/kernels/attention/test_flash_attn.py (varlen, paged KV, GQA, causal bottom-right).
+Tolerance: probabilities are rounded to the value dtype in both (oracle: normalised,
+kernel: flash-style unnormalised) so outputs differ by rounding noise only:
+one output ulp + 2e-3 * max|ref| (reference tests: atol 1.5e-2 / rtol 1e-2).
+"""
+import pytest
+import torch
+
+from tests.util import assert_close_rel, dev, make_kv_cache_x
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_ops as R  # noqa: E402
+
+
+def ops():
+    from vllm_metax_amd import _custom_ops
+    return _custom_ops
+
+
+def _run(q_lens, seq_lens, H, KVH, D, bs, dtype, seed=0, poison_tail=False):
+    torch.manual_seed(seed)
+    S = len(q_lens)
+    max_blocks = (max(seq_lens) + bs - 1) // bs
+    nb = S * max_blocks + 5
+    kc, vc = make_kv_cache_x(nb, bs, KVH, D, dtype, seed)
+    perm = torch.randperm(nb)
+    bt = torch.zeros(S, max_blocks, dtype=torch.int32)
+    for s in range(S):
+        for b in range(max_blocks):
+            bt[s, b] = int(perm[s * max_blocks + b])
+    cu = torch.zeros(S + 1, dtype=torch.int32)
+    cu[1:] = torch.tensor(q_lens).cumsum(0)
+    T = int(cu[-1])
+    scale = D ** -0.5
+    q = (torch.randn(T, H, D) * 0.5).to(dtype)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    ref = R.paged_prefill_attention(q, kc, vc, KVH, scale, bt, sl, cu)
+    if poison_tail:
+        for s, L in enumerate(seq_lens):
+            if L % bs:
+                blk = int(bt[s, (L - 1) // bs])
+                kc[blk, :, :, L % bs:, :] = float("nan")
+                vc[blk, :, :, L % bs:] = float("nan")
+    d = dev()
+    out = torch.full((T, H, D), float("nan"), dtype=dtype, device=d)
+    ops().paged_prefill_attention(out, q.to(d), kc.to(d), vc.to(d), KVH, scale, bt.to(d), sl.to(d),
+                                  cu.to(d), max(q_lens), bs)
+    torch.cuda.synchronize()
+    eps = {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7, torch.float32: 2.0 ** -23}[dtype]
+    assert_close_rel(out, ref, 2e-3, "prefill", abs_floor=eps * ref.float().abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("spec", [
+    ([1], [1]), ([5], [5]), ([16], [16]), ([17], [40]), ([128], [128]), ([129], [129]),
+    ([130, 7, 64], [130, 300, 64]),                   # pure prefill + chunked (context > 0)
+    ([32, 1, 200], [1000, 77, 200]),                  # mixed: long context, decode-like row
+    ([300], [813]),
+])
+def test_prefill_llama_heads(dtype, spec):
+    q_lens, seq_lens = spec
+    _run(q_lens, seq_lens, 8, 2, 128, 16, dtype, poison_tail=True)
+
+
+def test_prefill_gqa_32_8_chunk():
+    """Llama-3-8B heads (32/8): one 512-token chunk with 256 tokens of context."""
+    _run([512, 100], [768, 100], 32, 8, 128, 16, torch.bfloat16, seed=2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("D,bs", [(64, 16), (80, 8), (128, 32), (256, 16)])
+def test_prefill_generic_path(dtype, D, bs):
+    _run([9, 33], [20, 33], 4, 2, D, bs, dtype, seed=3)
+
+
+def test_prefill_matches_decode_kernel_on_last_token():
+    """Size-independent cross-check at the bench shape (8 seqs x 1024 new tokens): the last
+    query row of each sequence must equal paged_attention_v1 on the same cache."""
+    torch.manual_seed(5)
+    S, H, KVH, D, bs, L = 8, 32, 8, 128, 16, 1024
+    dtype = torch.bfloat16
+    d = dev()
+    nblk = L // bs
+    kc, vc = make_kv_cache_x(S * nblk, bs, KVH, D, dtype, 5)
+    kc, vc = kc.to(d), vc.to(d)
+    bt = torch.randperm(S * nblk).to(torch.int32).reshape(S, nblk).to(d)
+    cu = (torch.arange(S + 1, dtype=torch.int32) * L).to(d)
+    sl = torch.full((S,), L, dtype=torch.int32, device=d)
+    q = (torch.randn(S * L, H, D) * 0.5).to(dtype).to(d)
+    out = torch.empty_like(q)
+    scale = D ** -0.5
+    ops().paged_prefill_attention(out, q, kc, vc, KVH, scale, bt, sl, cu, L, bs)
+    last = torch.arange(S, device=d) * L + (L - 1)
+    dec = torch.empty(S, H, D, dtype=dtype, device=d)
+    ops().paged_attention_v1(dec, q[last].contiguous(), kc, vc, KVH, scale, bt, sl, bs, L, None, "auto")
+    eps = 2.0 ** -7
+    assert_close_rel(out[last], dec, 2e-3, "prefill vs decode", abs_floor=eps * dec.float().abs().max().item())
+    assert torch.isfinite(out.float()).all()

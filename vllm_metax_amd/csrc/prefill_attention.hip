@@ -1,0 +1,371 @@
+// prefill_attention.hip — paged prefill / chunked-prefill attention (varlen, causal
+// bottom-right aligned, GQA) over the SAME x-split paged KV cache the decode kernel reads.
+//
+// Reference call site: flash_attn_varlen_func(q, k=key_cache, v=value_cache,
+// block_table=..., cu_seqlens_q, seqused_k, causal=True) in
+// vllm_metax/v1/attention/backends/flash_attn.py:725-747 — the arithmetic lives in a closed
+// third-party wheel; semantics follow the reference's own oracle for that boundary,
+// tests/kernels/attention/test_flash_attn.py:27-80 (fp32 scores and softmax, probabilities
+// rounded to the value dtype, fp32 PV accumulation).
+//
+// MI355X design (fast path: head_size 128, block_size 16, 16-bit types):
+//   * one 256-thread workgroup = 128 consecutive query tokens of one (sequence, q-head);
+//     each wave owns 32 query rows (2 MFMA column tiles);
+//   * the x-split layout is MFMA-shaped by construction: a 16-token K block
+//     [d/8][16][8] is the A operand of S^T = K.Q^T (lane (lr,lc) <- chunk 4*ds+lr, token
+//     lc = 16 contiguous bytes), and a V block [d][16] is the A operand of O^T = V^T.P^T
+//     (lane <- row 16*dt+lc, tokens 4*lr..4*lr+3 = 8 contiguous bytes).  K/V blocks are
+//     copied verbatim global -> LDS (32 tokens per stage, double buffered) and every
+//     fragment read is lane-linear (bank-conflict free);
+//   * computing S^T (keys on rows, queries on columns) leaves each lane with 4+4 keys of ONE
+//     query column, which after exp() and rounding IS the B operand of the PV MFMA (k index
+//     = 8*lr + j <-> key (block j>>2, 4*lr + (j&3))): probabilities never leave registers;
+//   * online softmax: every accumulator register of a lane belongs to the same query column,
+//     so the rescale factor is one scalar per lane and column tile.
+#include "common.cuh"
+
+namespace mi355x {
+
+template <typename T>
+struct MfmaQK;
+template <>
+struct MfmaQK<bf16_t> {
+  static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+    bf16x2_t v = {static_cast<bf16_t>(lo), static_cast<bf16_t>(hi)};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+};
+template <>
+struct MfmaQK<f16_t> {
+  static __device__ __forceinline__ f32x4_t run(const uint4& a, const uint4& b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+    f16x2_t v = {static_cast<f16_t>(lo), static_cast<f16_t>(hi)};
+    return __builtin_bit_cast(uint32_t, v);
+  }
+};
+
+// keep the first `valid` (may be <= 0 or >= 4) 16-bit elements of a 4-element vector
+__device__ __forceinline__ uint2 zero_tail4(uint2 v, int valid) {
+  if (valid >= 4) return v;
+  if (valid <= 0) return make_uint2(0u, 0u);
+  if (valid == 1) return make_uint2(v.x & 0xFFFFu, 0u);
+  if (valid == 2) return make_uint2(v.x, 0u);
+  return make_uint2(v.x, v.y & 0xFFFFu);
+}
+
+constexpr int kPfD = 128;
+constexpr int kPfBS = 16;
+constexpr int kPfQTile = 128;   // query rows per workgroup
+constexpr int kPfKvTile = 32;   // keys per stage (2 cache blocks)
+constexpr float kNegBig = -1.0e30f;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
+    T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k_cache,
+    const T* __restrict__ v_cache, int num_heads, int num_kv_heads, float scale,
+    const int* __restrict__ block_tables, const int* __restrict__ seq_lens,
+    const int* __restrict__ cu_seqlens_q, int max_num_blocks_per_seq, int q_blocks_per_seq,
+    int64_t q_stride, int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [stage][K: 2 blocks x 4 KiB | V: 2 blocks x 4 KiB]
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+  constexpr int kStageVec = 4 * 4096 / 16;  // uint4 per stage (16 KiB)
+
+  const int seq = blockIdx.x / q_blocks_per_seq;
+  const int qb = blockIdx.x - seq * q_blocks_per_seq;
+  const int head = blockIdx.y;
+  const int q_begin = cu_seqlens_q[seq];
+  const int q_len = cu_seqlens_q[seq + 1] - q_begin;
+  const int m0 = qb * kPfQTile;
+  if (m0 >= q_len) return;
+  const int seq_len = seq_lens[seq];
+  const int ctx = seq_len - q_len;
+  const int kv_head = head / (num_heads / num_kv_heads);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lc = lane & 15;
+  const int lr = lane >> 4;
+
+  // ---- Q^T B-operand fragments: qf[qt][ds] = Q[row][32*ds + 8*lr .. +7] ----------------
+  uint4 qf[2][4];
+  int qrow[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    qrow[qt] = m0 + wave * 32 + qt * 16 + lc;
+    const int r = qrow[qt] < q_len ? qrow[qt] : q_len - 1;
+    const T* qp = q + (int64_t)(q_begin + r) * q_stride + (int64_t)head * kPfD + 8 * lr;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = *reinterpret_cast<const uint4*>(qp + 32 * ds);
+  }
+
+  f32x4_t oacc[2][8];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) oacc[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  float mrun[2] = {kNegBig, kNegBig};
+  float lrun[2] = {0.f, 0.f};  // per-lane partial sums (its own keys only)
+
+  // keys needed by this workgroup: [0, kv_end)
+  const int kv_end = min(seq_len, ctx + m0 + kPfQTile);
+  const int num_tiles = (kv_end + kPfKvTile - 1) / kPfKvTile;
+  const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+  const int num_seq_blocks = (seq_len + kPfBS - 1) / kPfBS;
+
+  // staging: thread t copies 16 B pieces t, t+256, t+512, t+768 of the stage image
+  // piece p: which = p >> 8 (0: K blk0, 1: K blk1, 2: V blk0, 3: V blk1), offset (p & 255)*16 B
+  uint4 stage_regs[4];
+  auto stage_load = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int blk = tile * 2 + (i & 1);
+      blk = blk < num_seq_blocks ? blk : num_seq_blocks - 1;
+      const int64_t pb = block_table[blk];
+      const T* base = (i < 2 ? k_cache : v_cache) + pb * kv_block_stride +
+                      (int64_t)kv_head * kv_head_stride;
+      stage_regs[i] = *reinterpret_cast<const uint4*>(base + tid * 8);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds[buf * kStageVec + i * 256 + tid] = stage_regs[i];
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+
+  // the wave's first query row decides which tiles it can skip entirely (causal)
+  const int wave_q_hi = ctx + m0 + wave * 32 + 31;  // last key any row of this wave may see
+
+  int cur = 0;
+  for (int tile = 0; tile < num_tiles; ++tile) {
+    const bool has_next = (tile + 1) < num_tiles;
+    if (has_next) stage_load(tile + 1);
+
+    const int t0 = tile * kPfKvTile;
+    if (t0 <= wave_q_hi) {
+      const uint4* kbuf = lds + cur * kStageVec;
+      const uint2* vbuf = reinterpret_cast<const uint2*>(lds + cur * kStageVec + 512);
+      // ---- S^T tiles: s[b][qt] = K_b . Q_qt^T, rows = keys 16*b + 4*lr + j, col = query lc
+      f32x4_t s[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) s[b][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+          const uint4 kf = kbuf[b * 256 + ds * 64 + lane];
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) s[b][qt] = MfmaQK<T>::run(kf, qf[qt][ds], s[b][qt]);
+        }
+      }
+      // ---- online softmax per query column ------------------------------------------
+      uint4 pfrag[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int limit = min(ctx + qrow[qt], seq_len - 1);  // last visible key of this row
+        float v[8];
+        float tmax = kNegBig;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int key = t0 + 16 * b + 4 * lr + j;
+            const float x = key <= limit ? s[b][qt][j] * scale : kNegBig;
+            v[b * 4 + j] = x;
+            tmax = fmaxf(tmax, x);
+          }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mnew = fmaxf(mrun[qt], tmax);
+        const float alpha = __expf(mrun[qt] - mnew);
+        mrun[qt] = mnew;
+        float psum = 0.f;
+        float p[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          p[i] = v[i] > 0.5f * kNegBig ? __expf(v[i] - mnew) : 0.f;
+          psum += p[i];
+        }
+        lrun[qt] = lrun[qt] * alpha + psum;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          oacc[qt][dt][0] *= alpha;
+          oacc[qt][dt][1] *= alpha;
+          oacc[qt][dt][2] *= alpha;
+          oacc[qt][dt][3] *= alpha;
+        }
+        pfrag[qt].x = MfmaQK<T>::pack(p[0], p[1]);
+        pfrag[qt].y = MfmaQK<T>::pack(p[2], p[3]);
+        pfrag[qt].z = MfmaQK<T>::pack(p[4], p[5]);
+        pfrag[qt].w = MfmaQK<T>::pack(p[6], p[7]);
+      }
+      // ---- O^T += V^T . P^T ------------------------------------------------------------
+      const bool tail = (t0 + kPfKvTile) > seq_len;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        // V block image [128 d][16 keys]: row 16*dt + lc, keys 4*lr..4*lr+3 -> 8 bytes
+        uint2 v0 = vbuf[(0 * 4096 + (16 * dt + lc) * 32 + 8 * lr) / 8];
+        uint2 v1 = vbuf[(1 * 4096 + (16 * dt + lc) * 32 + 8 * lr) / 8];
+        if (tail) {  // keys >= seq_len may hold NaN garbage: 0 * NaN must not reach O
+          v0 = zero_tail4(v0, seq_len - (t0 + 4 * lr));
+          v1 = zero_tail4(v1, seq_len - (t0 + 16 + 4 * lr));
+        }
+        const uint4 vf = make_uint4(v0.x, v0.y, v1.x, v1.y);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) oacc[qt][dt] = MfmaQK<T>::run(vf, pfrag[qt], oacc[qt][dt]);
+      }
+    }
+    if (has_next) stage_store(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l ----------------------------------------------
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = lrun[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qrow[qt] < q_len) {
+      T* op = out + (int64_t)(q_begin + qrow[qt]) * out_stride + (int64_t)head * kPfD + 4 * lr;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const uint2 v = make_uint2(MfmaQK<T>::pack(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv),
+                                   MfmaQK<T>::pack(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv));
+        *reinterpret_cast<uint2*>(op + 16 * dt) = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic fallback (any head size / block size / dtype): one wave per (query token, head),
+// lanes stride over keys, two passes (max+sum, then PV).  Correctness path only.
+template <typename T>
+__global__ __launch_bounds__(64) void paged_prefill_generic_kernel(
+    T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k_cache,
+    const T* __restrict__ v_cache, int num_heads, int num_kv_heads, int head_size,
+    int block_size, float scale, const int* __restrict__ block_tables,
+    const int* __restrict__ seq_lens, const int* __restrict__ cu_seqlens_q, int num_seqs,
+    int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* qs = reinterpret_cast<float*>(smem);  // [head_size]
+  const int tok = blockIdx.x;
+  const int head = blockIdx.y;
+  const int lane = threadIdx.x;
+  constexpr int X = 16 / sizeof(T);
+  // locate the sequence of this token (num_seqs is small; linear scan)
+  int seq = 0;
+  while (seq + 1 < num_seqs && cu_seqlens_q[seq + 1] <= tok) ++seq;
+  if (tok >= cu_seqlens_q[num_seqs]) return;
+  const int q_begin = cu_seqlens_q[seq];
+  const int q_len = cu_seqlens_q[seq + 1] - q_begin;
+  const int seq_len = seq_lens[seq];
+  const int visible = seq_len - q_len + (tok - q_begin) + 1;  // keys [0, visible)
+  const int kv_head = head / (num_heads / num_kv_heads);
+  const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+  for (int d = lane; d < head_size; d += 64) {
+    qs[d] = to_f32(q[(int64_t)tok * q_stride + (int64_t)head * head_size + d]);
+  }
+  __syncthreads();
+  auto kdot = [&](int key) {
+    const int64_t pb = block_table[key / block_size];
+    const int off = key % block_size;
+    const T* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+    float acc = 0.f;
+    for (int d = 0; d < head_size; ++d) {
+      acc += qs[d] * to_f32(kp[((d / X) * block_size + off) * X + (d % X)]);
+    }
+    return acc * scale;
+  };
+  float m = kNegBig;
+  for (int key = lane; key < visible; key += 64) m = fmaxf(m, kdot(key));
+  m = wave_max(m);
+  float lsum = 0.f;
+  for (int key = lane; key < visible; key += 64) lsum += __expf(kdot(key) - m);
+  lsum = wave_sum(lsum);
+  const float inv = 1.0f / lsum;
+  // PV: lanes over d, serial over keys (probabilities recomputed; rounded to T like the oracle)
+  for (int d = lane; d < head_size; d += 64) {
+    float acc = 0.f;
+    for (int key = 0; key < visible; ++key) {
+      const int64_t pb = block_table[key / block_size];
+      const int off = key % block_size;
+      const T* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+      const float p = to_f32(from_f32<T>(__expf(kdot(key) - m) * inv));
+      acc += p * to_f32(vp[(int64_t)d * block_size + off]);
+    }
+    out[(int64_t)tok * out_stride + (int64_t)head * head_size + d] = from_f32<T>(acc);
+  }
+}
+
+}  // namespace mi355x
+
+using namespace mi355x;
+
+extern "C" int mi355x_paged_prefill_attention(
+    void* out, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
+    const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
+    int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && head_size > 0 &&
+                     block_size > 0 && max_query_len >= 0,
+                 MI355X_EINVAL, "paged_prefill_attention: bad sizes");
+  MI355X_REQUIRE(num_heads % num_kv_heads == 0, MI355X_EINVAL,
+                 "paged_prefill_attention: num_heads %% num_kv_heads != 0");
+  if (num_seqs == 0 || max_query_len == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && query && key_cache && value_cache && block_tables && seq_lens &&
+                     cu_seqlens_q,
+                 MI355X_EINVAL, "paged_prefill_attention: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool fast = head_size == 128 && block_size == 16 && dtype != MI355X_F32 &&
+                    q_stride % 8 == 0 && out_stride % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(query) | reinterpret_cast<uintptr_t>(key_cache) |
+                      reinterpret_cast<uintptr_t>(value_cache)) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 7) == 0 && kv_block_stride % 8 == 0 &&
+                    kv_head_stride % 8 == 0;
+  if (fast) {
+    const int q_blocks = (max_query_len + kPfQTile - 1) / kPfQTile;
+    dim3 grid(num_seqs * q_blocks, num_heads), block(256);
+    const size_t smem = 2 * 4 * 4096;
+    return MI355X_DISPATCH_HALF(dtype, [&] {
+      hipLaunchKernelGGL(paged_prefill_d128_kernel<scalar_t>, grid, block, smem, s,
+                         static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query),
+                         static_cast<const scalar_t*>(key_cache),
+                         static_cast<const scalar_t*>(value_cache), num_heads, num_kv_heads, scale,
+                         block_tables, seq_lens, cu_seqlens_q, max_num_blocks_per_seq, q_blocks,
+                         q_stride, out_stride, kv_block_stride, kv_head_stride);
+      return check_launch("paged_prefill_attention");
+    });
+  }
+  // generic path needs the total number of query tokens: upper bound num_seqs * max_query_len
+  const int64_t max_tokens = (int64_t)num_seqs * max_query_len;
+  MI355X_REQUIRE(max_tokens <= 0x7fffffff, MI355X_EUNSUPPORTED, "paged_prefill_attention: too many tokens");
+  dim3 grid((int)max_tokens, num_heads), block(64);
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    hipLaunchKernelGGL(paged_prefill_generic_kernel<scalar_t>, grid, block,
+                       (size_t)head_size * sizeof(float), s, static_cast<scalar_t*>(out),
+                       static_cast<const scalar_t*>(query), static_cast<const scalar_t*>(key_cache),
+                       static_cast<const scalar_t*>(value_cache), num_heads, num_kv_heads, head_size,
+                       block_size, scale, block_tables, seq_lens, cu_seqlens_q, num_seqs,
+                       max_num_blocks_per_seq, q_stride, out_stride, kv_block_stride,
+                       kv_head_stride);
+    return check_launch("paged_prefill_attention(generic)");
+  });
+}

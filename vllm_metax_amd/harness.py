@@ -1,0 +1,325 @@
+"""Synthetic Llama-shaped caller of the hot path — the measurement harness's model.
+
+Stands in for the upstream-vLLM call stack that drives the reference's kernels
+(LlamaDecoderLayer.forward -> RMSNorm / QKV linear / rotary / cache write /
+attention / o_proj / RMSNorm / gate_up / SiluAndMul / down): the same sequence of ops, on
+synthetic weights of the named architecture (no checkpoints exist offline),
+with greedy sampling.  Every op on the hot path goes through the C-ABI
+(vllm_metax_amd._custom_ops); torch is used for allocation, the embedding gather, the
+un-quantised lm_head GEMM (library GEMM) and argmax.
+
+Decode steps are captured into a HIP graph (hipGraph via torch.cuda.CUDAGraph): all per-step
+index arithmetic (positions, slot mapping, sequence lengths) happens on the device inside
+the graph, so a replay is one host call.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import List, Optional
+
+import torch
+
+from . import _custom_ops as ops
+
+
+@dataclasses.dataclass
+class ModelConfig:
+    name: str = "llama-3-8b"
+    hidden: int = 4096
+    layers: int = 32
+    heads: int = 32
+    kv_heads: int = 8
+    head_dim: int = 128
+    ffn: int = 14336
+    vocab: int = 128256
+    rope_theta: float = 500000.0
+    eps: float = 1e-5
+    quant: str = "awq"          # "awq" | "gptq" | "fp8" | "none"
+    group_size: int = 128
+    tp: int = 1                 # tensor-parallel degree (heads / ffn sharded, all-reduce after o/down)
+
+    @staticmethod
+    def llama3_8b(quant="awq", tp=1):
+        return ModelConfig(quant=quant, tp=tp)
+
+    @staticmethod
+    def llama3_70b(quant="fp8", tp=8):
+        return ModelConfig(name="llama-3-70b", hidden=8192, layers=80, heads=64, kv_heads=8,
+                           ffn=28672, quant=quant, tp=tp)
+
+    @staticmethod
+    def qwen2_72b(quant="gptq", tp=8):
+        return ModelConfig(name="qwen2-72b", hidden=8192, layers=80, heads=64, kv_heads=8,
+                           ffn=29696, vocab=152064, rope_theta=1e6, eps=1e-6, quant=quant, tp=tp)
+
+    @staticmethod
+    def tiny(quant="awq"):
+        return ModelConfig(name="tiny", hidden=512, layers=2, heads=8, kv_heads=2, head_dim=64,
+                           ffn=1024, vocab=1024, quant=quant)
+
+
+class QLinear:
+    """One (column- or row-parallel shard of a) linear layer with synthetic weights."""
+
+    def __init__(self, k: int, n: int, cfg: ModelConfig, dtype, device, gen):
+        self.k, self.n, self.quant, self.group = k, n, cfg.quant, cfg.group_size
+        self.dtype = dtype
+        if cfg.quant == "awq":
+            qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (k, n // 8), dtype=torch.int32, device=device,
+                               generator=gen)
+            self.qweight = ops.awq_to_gptq_4bit(qw)                       # exllama layout
+            self.qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (k // self.group, n // 8),
+                                        dtype=torch.int32, device=device, generator=gen)
+            self.scales = (torch.rand(k // self.group, n, device=device, generator=gen) * 4e-3
+                           + 1e-3).to(dtype)
+        elif cfg.quant == "gptq":
+            self.qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (k // 8, n), dtype=torch.int32,
+                                         device=device, generator=gen)
+            ops.gptq_shuffle(self.qweight, torch.empty(0, dtype=torch.int32), 4)
+            self.qzeros = torch.full((k // self.group, n // 8), 0x77777777, dtype=torch.int32,
+                                     device=device)                       # symmetric (stored zero 7)
+            self.scales = (torch.rand(k // self.group, n, device=device, generator=gen) * 4e-3
+                           + 1e-3).to(dtype)
+            self.g_idx = torch.empty(0, dtype=torch.int32, device=device)
+        elif cfg.quant == "fp8":
+            w = torch.randn(n, k, device=device, generator=gen).clamp_(-448, 448)
+            self.weight = w.to(torch.float8_e4m3fn).t()                  # [K, N] column-major
+            self.w_scale = (torch.rand(1, n, device=device, generator=gen) * 4e-3 + 1e-3)
+        else:
+            self.weight = (torch.randn(k, n, device=device, generator=gen) * 0.02).to(dtype)
+        self._ws = {}
+
+    def _workspace(self, m: int, device):
+        ws = self._ws.get(m)
+        if ws is None:
+            ws = torch.empty(m, self.n, dtype=torch.float32, device=device)
+            self._ws[m] = ws
+        return ws
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        m = x.shape[0]
+        if self.quant == "awq":
+            ws = self._workspace(m, x.device) if m <= 64 else torch.empty(0)
+            return ops.awq_gemm(x, self.qweight, self.qzeros, self.scales, 8, ws,
+                                x.dtype == torch.bfloat16)
+        if self.quant == "gptq":
+            ws = self._workspace(m, x.device) if m <= 64 else torch.empty(0)
+            return ops.gptq_gemm(x, self.qweight, self.qzeros, self.scales, self.g_idx, True, 4,
+                                 self.group, torch.empty(0), ws, x.dtype == torch.bfloat16)
+        if self.quant == "fp8":
+            xq = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+            xs = torch.empty(m, 1, dtype=torch.float32, device=x.device)
+            ops.dynamic_per_token_scaled_fp8_quant(xq, x, xs, None)
+            out = torch.empty(m, self.n, dtype=x.dtype, device=x.device)
+            ops.cutlass_scaled_mm(out, xq, self.weight, xs, self.w_scale, None)
+            return out
+        return torch.matmul(x, self.weight)
+
+    def weight_bytes(self) -> int:
+        if self.quant in ("awq", "gptq"):
+            return self.k * self.n // 2 + (self.k // self.group) * self.n * 2 \
+                + (self.k // self.group) * self.n // 2
+        if self.quant == "fp8":
+            return self.k * self.n + self.n * 4
+        return self.k * self.n * 2
+
+
+class Layer:
+    def __init__(self, cfg: ModelConfig, dtype, device, gen):
+        h, d = cfg.hidden, cfg.head_dim
+        self.q_heads = cfg.heads // cfg.tp
+        self.kv_heads = max(cfg.kv_heads // cfg.tp, 1)
+        self.q_size, self.kv_size = self.q_heads * d, self.kv_heads * d
+        ffn = cfg.ffn // cfg.tp
+        self.qkv = QLinear(h, self.q_size + 2 * self.kv_size, cfg, dtype, device, gen)
+        self.o = QLinear(self.q_size, h, cfg, dtype, device, gen)
+        self.gate_up = QLinear(h, 2 * ffn, cfg, dtype, device, gen)
+        self.down = QLinear(ffn, h, cfg, dtype, device, gen)
+        self.ln1 = (torch.rand(h, device=device, generator=gen) * 0.2 + 0.9).to(dtype)
+        self.ln2 = (torch.rand(h, device=device, generator=gen) * 0.2 + 0.9).to(dtype)
+        self.ffn = ffn
+
+
+class HotPathModel:
+    """Weights + paged KV cache + the forward passes (prefill chunk / decode step)."""
+
+    BLOCK = 16
+
+    def __init__(self, cfg: ModelConfig, max_seqs: int, max_len: int, device="cuda:0",
+                 dtype=torch.bfloat16, seed: int = 0, tp_group=None):
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
+        self.tp_group = tp_group
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        self.layers: List[Layer] = [Layer(cfg, dtype, self.device, gen) for _ in range(cfg.layers)]
+        self.embed = (torch.randn(cfg.vocab, cfg.hidden, device=self.device, generator=gen)
+                      * 0.02).to(dtype)
+        vshard = cfg.vocab // cfg.tp
+        self.lm_head = (torch.randn(cfg.hidden, vshard, device=self.device, generator=gen)
+                        * 0.02).to(dtype)
+        self.final_norm = torch.ones(cfg.hidden, dtype=dtype, device=self.device)
+        d = cfg.head_dim
+        inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, device=self.device).float() / d))
+        t = torch.arange(max_len + 1, device=self.device).float()
+        fr = torch.outer(t, inv_freq)
+        self.cos_sin = torch.cat([fr.cos(), fr.sin()], dim=-1).to(dtype)
+        # paged KV cache, x-split layout: one (K, V) pair per layer
+        self.max_seqs, self.max_len = max_seqs, max_len
+        self.blocks_per_seq = (max_len + self.BLOCK - 1) // self.BLOCK
+        nb = max_seqs * self.blocks_per_seq
+        kvh = self.layers[0].kv_heads
+        x = 16 // torch.tensor([], dtype=dtype).element_size()
+        self.k_cache = [torch.zeros(nb, kvh, d // x, self.BLOCK, x, dtype=dtype, device=self.device)
+                        for _ in range(cfg.layers)]
+        self.v_cache = [torch.zeros(nb, kvh, d, self.BLOCK, dtype=dtype, device=self.device)
+                        for _ in range(cfg.layers)]
+        # block tables: a fixed random permutation of the pool (as the reference's tests do)
+        perm = torch.randperm(nb, device=self.device, generator=gen).to(torch.int32)
+        self.block_tables = perm.reshape(max_seqs, self.blocks_per_seq).contiguous()
+        self.scale = 1.0 / math.sqrt(d)
+        self._graph = None
+
+    # ---------------------------------------------------------------- helpers
+    def _all_reduce(self, x: torch.Tensor) -> torch.Tensor:
+        if self.tp_group is not None and self.cfg.tp > 1:
+            torch.distributed.all_reduce(x, group=self.tp_group)
+        return x
+
+    def _slots(self, seq_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+        blk = self.block_tables[seq_ids.long(), (positions // self.BLOCK).long()].long()
+        return blk * self.BLOCK + (positions % self.BLOCK)
+
+    def _layer(self, i: int, x: torch.Tensor, residual: Optional[torch.Tensor],
+               positions: torch.Tensor, slots: torch.Tensor, attn_fn):
+        L = self.layers[i]
+        cfg = self.cfg
+        if residual is None:
+            residual = x.clone()
+            h = torch.empty_like(x)
+            ops.rms_norm(h, x, L.ln1, cfg.eps)
+        else:
+            ops.fused_add_rms_norm(x, residual, L.ln1, cfg.eps)
+            h = x
+        qkv = L.qkv(h)
+        q = qkv[:, :L.q_size]
+        k = qkv[:, L.q_size:L.q_size + L.kv_size]
+        v = qkv[:, L.q_size + L.kv_size:]
+        ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin, True)
+        ops.reshape_and_cache(k.view(-1, L.kv_heads, cfg.head_dim), v.view(-1, L.kv_heads, cfg.head_dim),
+                              self.k_cache[i], self.v_cache[i], slots, "auto")
+        attn = attn_fn(i, q.view(-1, L.q_heads, cfg.head_dim))
+        o = self._all_reduce(L.o(attn.view(-1, L.q_size)))
+        ops.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
+        gu = L.gate_up(o)
+        act = torch.empty(gu.shape[0], L.ffn, dtype=gu.dtype, device=gu.device)
+        ops.silu_and_mul(act, gu)
+        out = self._all_reduce(L.down(act))
+        return out, residual
+
+    def _logits_argmax(self, x: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
+        ops.fused_add_rms_norm(x, residual, self.final_norm, self.cfg.eps)
+        logits = torch.matmul(x, self.lm_head)
+        if self.tp_group is not None and self.cfg.tp > 1:
+            parts = [torch.empty_like(logits) for _ in range(self.cfg.tp)]
+            torch.distributed.all_gather(parts, logits, group=self.tp_group)
+            logits = torch.cat(parts, dim=-1)
+        return logits.argmax(dim=-1)
+
+    # ---------------------------------------------------------------- prefill
+    def prefill(self, token_ids: torch.Tensor, seq_ids: List[int], context_len: int = 0):
+        """One prefill chunk: `token_ids` [n_seqs, q_len] new tokens for the sequences `seq_ids`,
+        each with `context_len` tokens already cached.  Returns the next token per sequence."""
+        n, q_len = token_ids.shape
+        dev = self.device
+        sid = torch.tensor(seq_ids, dtype=torch.int64, device=dev)
+        pos = (torch.arange(q_len, device=dev) + context_len).repeat(n)
+        seq_of_tok = sid.repeat_interleave(q_len)
+        slots = self._slots(seq_of_tok, pos)
+        cu = (torch.arange(n + 1, device=dev, dtype=torch.int32) * q_len)
+        seq_lens = torch.full((n,), context_len + q_len, dtype=torch.int32, device=dev)
+        bt = self.block_tables[sid]
+        x = self.embed[token_ids.reshape(-1)]
+        residual = None
+
+        def attn_fn(i, q3):
+            out = torch.empty_like(q3)
+            ops.paged_prefill_attention(out, q3, self.k_cache[i], self.v_cache[i],
+                                        self.layers[i].kv_heads, self.scale, bt, seq_lens, cu,
+                                        q_len, self.BLOCK)
+            return out
+
+        for i in range(self.cfg.layers):
+            x, residual = self._layer(i, x, residual, pos, slots, attn_fn)
+        last = (cu[1:] - 1).long()
+        return self._logits_argmax(x[last].contiguous(), residual[last].contiguous())
+
+    # ----------------------------------------------------------------- decode
+    def setup_decode(self, num_seqs: int, start_len: int, max_seq_len: int):
+        """Allocate the static decode state (all sequences active, equal length)."""
+        dev = self.device
+        self.d_tokens = torch.zeros(num_seqs, dtype=torch.int64, device=dev)
+        self.d_positions = torch.full((num_seqs,), start_len, dtype=torch.int64, device=dev)
+        self.d_seq_lens = torch.full((num_seqs,), start_len + 1, dtype=torch.int32, device=dev)
+        self.d_seq_ids = torch.arange(num_seqs, dtype=torch.int64, device=dev)
+        self.d_bt = self.block_tables[:num_seqs].contiguous()
+        self.d_max_seq_len = max_seq_len
+        H = self.layers[0].q_heads
+        P = (max_seq_len + ops.PARTITION_SIZE - 1) // ops.PARTITION_SIZE
+        self.d_tmp = torch.empty(num_seqs, H, P, self.cfg.head_dim, dtype=self.dtype, device=dev)
+        self.d_es = torch.empty(num_seqs, H, P, dtype=torch.float32, device=dev)
+        self.d_ml = torch.empty_like(self.d_es)
+        self._graph = None
+
+    def set_decode_lengths(self, lengths: torch.Tensor):
+        """positions[s] = lengths[s] (index of the token being decoded), seq_lens = lengths + 1."""
+        self.d_positions.copy_(lengths.to(torch.int64))
+        self.d_seq_lens.copy_((lengths + 1).to(torch.int32))
+
+    def _decode_body(self):
+        slots = self._slots(self.d_seq_ids, self.d_positions)
+        x = self.embed[self.d_tokens]
+        residual = None
+
+        def attn_fn(i, q3):
+            out = torch.empty_like(q3)
+            ops.paged_attention_v2(out, self.d_es, self.d_ml, self.d_tmp, q3, self.k_cache[i],
+                                   self.v_cache[i], self.layers[i].kv_heads, self.scale, self.d_bt,
+                                   self.d_seq_lens, self.BLOCK, self.d_max_seq_len, None, "auto")
+            return out
+
+        for i in range(self.cfg.layers):
+            x, residual = self._layer(i, x, residual, self.d_positions, slots, attn_fn)
+        nxt = self._logits_argmax(x, residual)
+        self.d_tokens.copy_(nxt)
+        self.d_positions.add_(1)
+        self.d_seq_lens.add_(1)
+
+    def decode_step(self, use_graph: bool = True):
+        if not use_graph:
+            self._decode_body()
+            return
+        if self._graph is None:
+            # warm up on a side stream, then capture
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            saved = (self.d_tokens.clone(), self.d_positions.clone(), self.d_seq_lens.clone())
+            with torch.cuda.stream(s):
+                self._decode_body()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.d_tokens.copy_(saved[0]); self.d_positions.copy_(saved[1]); self.d_seq_lens.copy_(saved[2])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._decode_body()
+            self._graph = g
+            self.d_tokens.copy_(saved[0]); self.d_positions.copy_(saved[1]); self.d_seq_lens.copy_(saved[2])
+        self._graph.replay()
+
+    # -------------------------------------------------------------- accounting
+    def decode_step_bytes(self, mean_len: float, num_seqs: int) -> dict:
+        """Algorithmic HBM bytes of one decode step."""
+        L = self.layers[0]
+        w = sum(l.weight_bytes() for l in (L.qkv, L.o, L.gate_up, L.down)) * self.cfg.layers
+        kv = num_seqs * mean_len * L.kv_heads * self.cfg.head_dim * 2 * 2 * self.cfg.layers
+        head = self.lm_head.numel() * 2
+        return {"weights": w, "kv": kv, "lm_head": head, "total": w + kv + head}
