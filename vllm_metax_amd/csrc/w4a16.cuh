@@ -57,10 +57,9 @@ __device__ __forceinline__ uint4 dequant_word(uint32_t w, float s, float zs) {
 
 enum ZeroMode { kZeroAwq = 0, kZeroGptq = 1 };
 
-// zero points of the 4 columns n .. n+3 (n % 4 == 0) of group row `zrow`
+// zero points of the 4 columns n .. n+3 (n % 4 == 0) from their packed word
 template <int ZMODE>
-__device__ __forceinline__ void load_zeros4(const uint32_t* __restrict__ zrow, int n, float (&z)[4]) {
-  const uint32_t w = zrow[n >> 3];
+__device__ __forceinline__ void unpack_zeros4(uint32_t w, int n, float (&z)[4]) {
   const int base = n & 7;  // 0 or 4
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -73,7 +72,10 @@ __device__ __forceinline__ void load_zeros4(const uint32_t* __restrict__ zrow, i
     }
   }
 }
-
+template <int ZMODE>
+__device__ __forceinline__ void load_zeros4(const uint32_t* __restrict__ zrow, int n, float (&z)[4]) {
+  unpack_zeros4<ZMODE>(zrow[n >> 3], n, z);
+}
 
 struct GemmArgs {
   void* c;

@@ -159,7 +159,7 @@ constexpr int kSmBN = 64;
 constexpr int kSmThreads = 256;
 
 template <typename T, int MT, int ZMODE>
-__global__ __launch_bounds__(kSmThreads) void w4a16_gemm_small_m_kernel(
+__global__ __launch_bounds__(kSmThreads, 3) void w4a16_gemm_small_m_kernel(
     T* __restrict__ c, float* __restrict__ acc_ws, const T* __restrict__ a,
     const uint32_t* __restrict__ qw, const T* __restrict__ scales,
     const uint32_t* __restrict__ qz, int m, int n, int k, int group, int64_t lda,
@@ -195,27 +195,50 @@ __global__ __launch_bounds__(kSmThreads) void w4a16_gemm_small_m_kernel(
   }
   const int n8 = n >> 3;
 
-  for (int s = step_begin + wave; s < step_end; s += 4) {
+  // Software pipeline, depth 2: the loads of k-step s+4 (this wave's next step) are issued
+  // before the dequant + MFMA work of step s, so HBM / L2 latency hides under compute.
+  struct Stage {
+    uint4 b;        // 4 shuffled words: columns ncol..ncol+3, k-rows 8*(4s+lr)..+7
+    uint4 a[MT];    // A fragments of the MT row tiles
+    uint2 sc;       // 4 scales (scalar_t) of this step's group
+    uint32_t zw;    // packed zero points word
+  };
+  auto load_stage = [&](Stage& st, int s) {
     const int kbase = s * 32;
     const int g = kbase / group;
-    const uint4 bw = *reinterpret_cast<const uint4*>(qw + (int64_t)(4 * s + lr) * n + ncol);
-    uint4 af[MT];
+    st.b = *reinterpret_cast<const uint4*>(qw + (int64_t)(4 * s + lr) * n + ncol);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(arow[i] + kbase);
-    // per-column scale / zero of this k-step's group
-    float sc[4], zp[4];
-    {
-      const T* sp = scales + (int64_t)g * n + ncol;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) sc[t] = to_f32(sp[t]);
-      load_zeros4<ZMODE>(qz + (int64_t)g * n8, ncol, zp);
-    }
-    const uint32_t words[4] = {bw.x, bw.y, bw.z, bw.w};
+    for (int i = 0; i < MT; ++i) st.a[i] = *reinterpret_cast<const uint4*>(arow[i] + kbase);
+    st.sc = *reinterpret_cast<const uint2*>(scales + (int64_t)g * n + ncol);
+    st.zw = qz[(int64_t)g * n8 + (ncol >> 3)];
+  };
+  auto compute_stage = [&](const Stage& st) {
+    T sct[4];
+    *reinterpret_cast<uint2*>(sct) = st.sc;
+    float zp[4];
+    unpack_zeros4<ZMODE>(st.zw, ncol, zp);
+    const uint32_t words[4] = {st.b.x, st.b.y, st.b.z, st.b.w};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const uint4 bf = dequant_word<T>(words[t], sc[t], -zp[t] * sc[t]);
+      const float sc = to_f32(sct[t]);
+      const uint4 bf = dequant_word<T>(words[t], sc, -zp[t] * sc);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][t] = Mfma<T>::run(af[i], bf, acc[i][t]);
+      for (int i = 0; i < MT; ++i) acc[i][t] = Mfma<T>::run(st.a[i], bf, acc[i][t]);
+    }
+  };
+  {
+    Stage s0, s1;
+    int s = step_begin + wave;
+    if (s < step_end) load_stage(s0, s);
+    while (s < step_end) {
+      const bool more1 = (s + 4) < step_end;
+      if (more1) load_stage(s1, s + 4);
+      compute_stage(s0);
+      if (!more1) break;
+      const bool more2 = (s + 8) < step_end;
+      if (more2) load_stage(s0, s + 8);
+      compute_stage(s1);
+      s += 8;
     }
   }
 
@@ -277,11 +300,14 @@ __global__ __launch_bounds__(kSmThreads) void w4a16_gemm_small_m_kernel(
   }
 }
 
+// split-K epilogue: out = T(ws); ws is handed back ZEROED, which is the state the caller must
+// provide it in (the reference's temp_space is a fresh torch.zeros, awq.py:140-147).
 template <typename T>
-__global__ void f32_to_t_kernel(T* __restrict__ out, const float* __restrict__ in, int64_t n4) {
+__global__ void f32_to_t_kernel(T* __restrict__ out, float* __restrict__ in, int64_t n4) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const float4 v = reinterpret_cast<const float4*>(in)[i];
+  reinterpret_cast<float4*>(in)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   T o[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
   if constexpr (sizeof(T) == 2) {
     reinterpret_cast<uint2*>(out)[i] = *reinterpret_cast<const uint2*>(o);
@@ -298,22 +324,16 @@ static int launch_small_m(const GemmArgs& g, int row0, int rows) {
   T* c = static_cast<T*>(g.c) + (int64_t)row0 * g.n;
   const int col_tiles = g.n / kSmBN;
   const int total_steps = g.k / 32;
-  // split K across workgroups until ~2 workgroups per CU, keeping >= 8 k-steps per wave
+  // Split K across workgroups only when the column tiles alone cannot fill the chip: every
+  // extra split adds rows*n fp32 atomics (~1.3 TB/s chip-wide).  Keep >= 16 k-steps per split.
   int sk = 1;
   const bool can_split = g.ws != nullptr && g.ws_elems >= (int64_t)rows * g.n;
   if (can_split) {
-    while (col_tiles * sk < 512 && total_steps / (sk * 2) >= 32) sk *= 2;
+    while (col_tiles * sk < 256 && total_steps / (sk * 2) >= 16) sk *= 2;
   }
   const int steps_per_split = (total_steps + sk - 1) / sk;
   sk = (total_steps + steps_per_split - 1) / steps_per_split;
   float* ws = g.ws;
-  if (sk > 1) {
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)rows * g.n * sizeof(float), g.stream);
-    if (e != hipSuccess) {
-      set_error("w4a16_gemm: hipMemsetAsync: %s", hipGetErrorString(e));
-      return MI355X_ELAUNCH;
-    }
-  }
   const int mt = (rows + 15) / 16;
   dim3 grid(col_tiles, sk), block(kSmThreads);
 #define LAUNCH_SM(MTV)                                                                      \
