@@ -1,0 +1,16 @@
+"""Single-shape driver for rocprofv3 PMC runs of the small-M w4a16 GEMM (gate_up, M=64)."""
+import sys, torch
+sys.path.insert(0, ".")
+from vllm_metax_amd import _custom_ops as ops
+d = torch.device("cuda:0")
+M, K, N, g = 64, 4096, 28672, 128
+if len(sys.argv) > 1:
+    M = int(sys.argv[1])
+qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=d).view(N, K // 8)
+qz = torch.randint(-2**31, 2**31 - 1, (K // g, N // 8), dtype=torch.int32, device=d)
+sc = (torch.rand(K // g, N, device=d) * 4e-3 + 1e-3).to(torch.bfloat16)
+x = (torch.randn(M, K, device=d) * 0.5).to(torch.bfloat16)
+copies = [qw.clone() for _ in range(6)]
+for i in range(12):
+    ops.awq_gemm(x, copies[i % 6], qz, sc, 8, torch.empty(0), True)
+torch.cuda.synchronize()

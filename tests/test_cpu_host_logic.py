@@ -1,0 +1,102 @@
+"""CPU: host-side logic of the plugin that needs no GPU and no vLLM — attention metadata
+(decode / prefill split), KV-cache views, platform capability flags and KV-pool sizing,
+env registry, entry points, harness accounting."""
+import pytest
+import torch
+
+import vllm_metax_amd
+from vllm_metax_amd import envs
+from vllm_metax_amd.attention import backend as B
+from vllm_metax_amd.platform import Mi355xPlatform
+
+
+def test_entry_points():
+    assert vllm_metax_amd.register() == "vllm_metax_amd.platform.Mi355xPlatform"
+    assert vllm_metax_amd.register_patch() is None and vllm_metax_amd.register_model() is None
+
+
+def test_split_decodes_and_prefills():
+    assert B.split_decodes_and_prefills([1, 1, 1]) == (3, 0, 3, 0)
+    assert B.split_decodes_and_prefills([1, 1, 7, 300]) == (2, 2, 2, 307)
+    assert B.split_decodes_and_prefills([5, 9]) == (0, 2, 0, 14)
+    assert B.split_decodes_and_prefills([]) == (0, 0, 0, 0)
+    # a decode after the first prefill is treated as a (1-token) prefill, as upstream does
+    assert B.split_decodes_and_prefills([1, 8, 1]) == (1, 2, 1, 9)
+
+
+def test_build_metadata_mixed_batch():
+    qsl = torch.tensor([0, 1, 2, 34, 234], dtype=torch.int32)
+    seq_lens = torch.tensor([40, 1100, 32, 713], dtype=torch.int32)
+    bt = torch.zeros(4, 70, dtype=torch.int32)
+    slots = torch.arange(234, dtype=torch.int64)
+    md = B.build_metadata(qsl, qsl.tolist(), seq_lens, seq_lens.tolist(), bt, slots, 234, 200, 1100,
+                          num_heads=32, head_size=128, dtype=torch.bfloat16)
+    assert (md.num_decodes, md.num_decode_tokens, md.num_prefills, md.num_prefill_tokens) == (2, 2, 2, 232)
+    assert md.max_decode_seq_len == 1100 and md.max_prefill_query_len == 200
+    assert md.prefill_query_start_loc.tolist() == [0, 32, 232]
+    assert md.exp_sums.shape == (2, 32, 3) and md.tmp_out.shape == (2, 32, 3, 128)
+    md2 = B.build_metadata(qsl[:3], [0, 1, 2], seq_lens[:2], [40, 1100], bt[:2], slots[:2], 2, 1, 1100,
+                           32, 128, torch.bfloat16)
+    assert md2.num_prefills == 0 and md2.prefill_query_start_loc is None
+
+
+def test_kv_cache_views():
+    shape = B.kv_cache_shape(10, 16, 8, 128)
+    assert shape == (2, 10, 16 * 8 * 128)
+    kv = torch.arange(2 * 10 * 16 * 8 * 128, dtype=torch.float32).to(torch.bfloat16).reshape(shape)
+    kc, vc = B.split_kv_cache(kv, 8, 128)
+    assert kc.shape == (10, 8, 16, 16, 8) and vc.shape == (10, 8, 128, 16)
+    assert kc.data_ptr() == kv[0].data_ptr() and vc.data_ptr() == kv[1].data_ptr()
+    assert kc.stride(0) == vc.stride(0) == 16 * 8 * 128
+
+
+def test_platform_flags_and_kv_sizing():
+    P = Mi355xPlatform
+    assert P.supports_fp8() is True and P.use_custom_allreduce() is False
+    assert P.dist_backend == "nccl" and "awq" in P.supported_quantization and "gptq" in P.supported_quantization
+    assert P.get_attn_backend_cls(None, 128, torch.bfloat16, "auto", 16, True, False).endswith(
+        "Mi355xPagedAttentionBackend")
+    with pytest.raises(ValueError, match="kv cache"):
+        P.get_attn_backend_cls(None, 128, torch.bfloat16, "fp8", 16, True, False)
+    with pytest.raises(NotImplementedError):
+        P.get_attn_backend_cls(None, 128, torch.bfloat16, "auto", 16, True, True)
+    # Llama-3-70B at TP=8 -> 80 layers x 1 kv head x 128 x 2 (K,V) x 2 B = 40 960 B/token
+    assert P.kv_bytes_per_token(80, 1, 128) == 40960
+    toks = P.kv_pool_tokens(weight_bytes=int(70e9 / 8), num_layers=80, num_kv_heads=1, head_size=128)
+    assert toks % 16 == 0 and 5_500_000 < toks < 6_300_000     # "~6 M tokens/rank"
+    assert P.kv_pool_tokens(weight_bytes=400 * 10 ** 9, num_layers=80, num_kv_heads=1, head_size=128) == 0
+
+    class Cfg:  # minimal stand-in for VllmConfig
+        class parallel_config:
+            worker_cls = "auto"
+
+        class cache_config:
+            block_size = None
+
+        class model_config:
+            disable_cascade_attn = False
+    P.check_and_update_config(Cfg)
+    assert Cfg.parallel_config.worker_cls == "vllm.v1.worker.gpu_worker.Worker"
+    assert Cfg.cache_config.block_size == 16 and Cfg.model_config.disable_cascade_attn is True
+
+
+def test_envs_registry(monkeypatch):
+    assert envs.MI355X_PA_ALLOW_V1 is False
+    monkeypatch.setenv("MI355X_MAX_BATCHED_TOKENS", "4096")
+    assert envs.MI355X_MAX_BATCHED_TOKENS == 4096
+    with pytest.raises(AttributeError):
+        envs.NOT_A_KNOB
+
+
+def test_harness_accounting_matches_baseline_md():
+    """Llama-3-8B AWQ per-layer weights ~109 MB (+4.3 MB scales/zeros);
+    attention decode 285 MB / layer at batch 64, mean context 1088."""
+    from vllm_metax_amd import harness
+    cfg = harness.ModelConfig.llama3_8b("awq")
+    shapes = [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)]
+    wbytes = sum(k * n // 2 for k, n in shapes)
+    assert abs(wbytes - 109e6) / 109e6 < 0.01
+    meta = sum((k // 128) * n * 2 + (k // 128) * n // 2 for k, n in shapes)
+    assert abs(meta - 4.3e6) / 4.3e6 < 0.05
+    kv = 64 * 1088 * cfg.kv_heads * cfg.head_dim * 2 * 2
+    assert abs(kv - 285e6) / 285e6 < 0.01

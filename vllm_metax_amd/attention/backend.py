@@ -1,0 +1,240 @@
+"""Attention backend of the MI355X plugin: paged attention over the x-split KV cache.
+
+Structure follows the reference's smallest complete backend, triton_attn.py (metadata
+dataclass :38-65, builder with full-graph support :68-146, backend class :149-203, impl that
+writes the KV cache and then runs attention on query[:num_actual_tokens] :267-373), with the
+decode / prefill split of its default backend (flash_attn.py:343-379, split computed in build())
+— but WITHOUT that backend's per-layer host syncs (flash_attn.py:726-730 `.tolist()` +
+cumsum): every index tensor the kernels need is derived once per step in `build_metadata`.
+
+KV cache: shape (2, num_blocks, block_size * num_kv_heads * head_size); plane 0 is viewed as
+[nb, kvh, d/x, bs, x] (keys), plane 1 as [nb, kvh, d, bs] (values) — the layout
+reshape_and_cache / paged_attention_v1/v2 are defined on (csrc/cache_kernels.cu:203-255,
+attention_kernels.cuh:86-89).
+
+The core (`build_metadata`, `paged_attention_forward`) has no vLLM dependency; the vLLM-facing
+classes at the bottom are thin and only defined when vLLM imports.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Optional, Tuple
+
+import torch
+
+from .. import _custom_ops as ops
+
+PARTITION_SIZE = ops.PARTITION_SIZE
+
+
+@dataclasses.dataclass
+class Mi355xPagedMetadata:
+    # |---------------- seq_len ----------------|
+    # |------ context_len ------|-- query_len --|
+    num_actual_tokens: int          # tokens excluding graph padding
+    max_query_len: int
+    max_seq_len: int
+    query_start_loc: torch.Tensor   # int32 [R+1]
+    seq_lens: torch.Tensor          # int32 [R]
+    block_table: torch.Tensor       # int32 [R, max_blocks]
+    slot_mapping: torch.Tensor      # int64 [T]
+    # decode-first split (requests with query_len == 1 come first)
+    num_decodes: int = 0
+    num_decode_tokens: int = 0
+    num_prefills: int = 0
+    num_prefill_tokens: int = 0
+    max_decode_seq_len: int = 0
+    max_prefill_query_len: int = 0
+    prefill_query_start_loc: Optional[torch.Tensor] = None  # int32 [Rp+1], rebased to 0
+    # split-KV workspaces for the decode kernel (allocated once per step, shared by all layers)
+    exp_sums: Optional[torch.Tensor] = None
+    max_logits: Optional[torch.Tensor] = None
+    tmp_out: Optional[torch.Tensor] = None
+
+
+def split_decodes_and_prefills(query_lens_cpu, decode_threshold: int = 1) -> Tuple[int, int, int, int]:
+    """Same contract as upstream's helper used at flash_attn.py:307-314: the batch is already
+    ordered decode-first; returns (num_decodes, num_prefills, num_decode_tokens,
+    num_prefill_tokens) where decodes are the leading requests with query_len <= threshold."""
+    q = [int(v) for v in query_lens_cpu]
+    n = len(q)
+    first_prefill = n
+    for i, v in enumerate(q):
+        if v > decode_threshold:
+            first_prefill = i
+            break
+    num_decodes = first_prefill
+    num_decode_tokens = sum(q[:first_prefill])
+    return num_decodes, n - num_decodes, num_decode_tokens, sum(q) - num_decode_tokens
+
+
+def build_metadata(query_start_loc: torch.Tensor, query_start_loc_cpu, seq_lens: torch.Tensor,
+                   seq_lens_cpu, block_table: torch.Tensor, slot_mapping: torch.Tensor,
+                   num_actual_tokens: int, max_query_len: int, max_seq_len: int, num_heads: int,
+                   head_size: int, dtype: torch.dtype) -> Mi355xPagedMetadata:
+    """Everything forward() needs, computed once per step (cf. flash_attn.py:286-526).
+    `*_cpu` are host copies (lists / CPU tensors) that vLLM's CommonAttentionMetadata already
+    carries, so no device->host sync happens here either."""
+    qsl = [int(v) for v in query_start_loc_cpu]
+    q_lens = [qsl[i + 1] - qsl[i] for i in range(len(qsl) - 1)]
+    nd, npf, ndt, npt = split_decodes_and_prefills(q_lens)
+    sl_cpu = [int(v) for v in seq_lens_cpu]
+    md = Mi355xPagedMetadata(
+        num_actual_tokens=num_actual_tokens, max_query_len=max_query_len, max_seq_len=max_seq_len,
+        query_start_loc=query_start_loc, seq_lens=seq_lens, block_table=block_table,
+        slot_mapping=slot_mapping, num_decodes=nd, num_decode_tokens=ndt, num_prefills=npf,
+        num_prefill_tokens=npt)
+    dev = seq_lens.device
+    if nd > 0:
+        md.max_decode_seq_len = max(sl_cpu[:nd]) if sl_cpu else 0
+        parts = max((md.max_decode_seq_len + PARTITION_SIZE - 1) // PARTITION_SIZE, 1)
+        md.exp_sums = torch.empty(nd, num_heads, parts, dtype=torch.float32, device=dev)
+        md.max_logits = torch.empty_like(md.exp_sums)
+        md.tmp_out = torch.empty(nd, num_heads, parts, head_size, dtype=dtype, device=dev)
+    if npf > 0:
+        md.max_prefill_query_len = max(q_lens[nd:])
+        md.prefill_query_start_loc = (query_start_loc[nd:] - query_start_loc[nd:nd + 1]).to(torch.int32)
+    return md
+
+
+def kv_cache_shape(num_blocks: int, block_size: int, num_kv_heads: int, head_size: int) -> Tuple[int, ...]:
+    return (2, num_blocks, block_size * num_kv_heads * head_size)
+
+
+def split_kv_cache(kv_cache: torch.Tensor, num_kv_heads: int, head_size: int):
+    """(2, nb, bs*kvh*d) -> key_cache [nb, kvh, d/x, bs, x], value_cache [nb, kvh, d, bs]."""
+    x = 16 // kv_cache.element_size()
+    nb = kv_cache.shape[1]
+    key_cache = kv_cache[0].view(nb, num_kv_heads, head_size // x, -1, x)
+    value_cache = kv_cache[1].view(nb, num_kv_heads, head_size, -1)
+    return key_cache, value_cache
+
+
+def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
+                            value: Optional[torch.Tensor], kv_cache: torch.Tensor,
+                            md: Mi355xPagedMetadata, output: torch.Tensor, num_kv_heads: int,
+                            scale: float, alibi_slopes: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """query [T, H, d], key/value [T, KVH, d] (may be padded past num_actual_tokens),
+    output [T, H, d] caller-provided (accept_output_buffer, flash_attn.py:56)."""
+    head_size = query.shape[-1]
+    key_cache, value_cache = split_kv_cache(kv_cache, num_kv_heads, head_size)
+    block_size = key_cache.shape[3]
+    n = md.num_actual_tokens
+    if key is not None and value is not None:
+        # slot_mapping.size(0) is the number of real tokens (cache_kernels.cu:459-469)
+        ops.reshape_and_cache(key, value, key_cache, value_cache, md.slot_mapping[:n], "auto")
+    nd, ndt = md.num_decodes, md.num_decode_tokens
+    if nd > 0:
+        ops.paged_attention_v2(output[:ndt], md.exp_sums, md.max_logits, md.tmp_out, query[:ndt],
+                               key_cache, value_cache, num_kv_heads, scale, md.block_table[:nd],
+                               md.seq_lens[:nd], block_size, md.max_decode_seq_len, alibi_slopes,
+                               "auto")
+    if md.num_prefills > 0:
+        if alibi_slopes is not None:
+            raise RuntimeError("ALiBi is only supported on the decode path of this backend")
+        ops.paged_prefill_attention(output[ndt:n], query[ndt:n], key_cache, value_cache,
+                                    num_kv_heads, scale, md.block_table[nd:], md.seq_lens[nd:],
+                                    md.prefill_query_start_loc, md.max_prefill_query_len, block_size)
+    return output
+
+
+# --------------------------------------------------------------------------- vLLM-facing
+try:  # pragma: no cover - needs upstream vLLM
+    from vllm.attention.backends.abstract import AttentionBackend, AttentionImpl, AttentionType
+    from vllm.v1.attention.backends.utils import (AttentionCGSupport, AttentionMetadataBuilder,
+                                                  CommonAttentionMetadata)
+
+    class Mi355xPagedMetadataBuilder(AttentionMetadataBuilder[Mi355xPagedMetadata]):
+        cudagraph_support = AttentionCGSupport.ALWAYS      # cf. triton_attn.py:69
+        reorder_batch_threshold = 1                         # decode-first batches
+
+        def __init__(self, kv_cache_spec, layer_names, vllm_config, device):
+            super().__init__(kv_cache_spec, layer_names, vllm_config, device)
+            mc = vllm_config.model_config
+            self.num_heads = mc.get_num_attention_heads(vllm_config.parallel_config)
+            self.head_size = mc.get_head_size()
+            self.dtype = mc.dtype
+
+        def build_for_cudagraph_capture(self, common_attn_metadata):
+            md = self.build(0, common_attn_metadata)
+            md.seq_lens.fill_(1)                            # cf. triton_attn.py:93-99
+            return md
+
+        def build(self, common_prefix_len, common_attn_metadata: "CommonAttentionMetadata",
+                  fast_build: bool = False):
+            c = common_attn_metadata
+            return build_metadata(c.query_start_loc, c.query_start_loc_cpu, c.seq_lens,
+                                  c.seq_lens_cpu, c.block_table_tensor, c.slot_mapping,
+                                  c.num_actual_tokens, c.max_query_len, c.max_seq_len,
+                                  self.num_heads, self.head_size, self.dtype)
+
+    class Mi355xPagedAttentionImpl(AttentionImpl):
+        def __init__(self, num_heads, head_size, scale, num_kv_heads, alibi_slopes, sliding_window,
+                     kv_cache_dtype, logits_soft_cap=None, attn_type=AttentionType.DECODER,
+                     kv_sharing_target_layer_name=None, **kwargs):
+            if kv_cache_dtype != "auto":
+                raise ValueError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+            if sliding_window is not None or logits_soft_cap:
+                raise NotImplementedError("sliding window / soft-cap are out of scope")
+            if attn_type != AttentionType.DECODER:
+                raise NotImplementedError("only decoder self-attention is supported")
+            self.num_heads, self.head_size, self.scale = num_heads, head_size, float(scale)
+            self.num_kv_heads = num_kv_heads
+            self.alibi_slopes = (torch.tensor(alibi_slopes, dtype=torch.float32)
+                                 if alibi_slopes is not None else None)
+
+        def forward(self, layer, query, key, value, kv_cache, attn_metadata, output=None,
+                    output_scale=None, output_block_scale=None):
+            assert output is not None, "Output tensor must be provided."
+            if attn_metadata is None:                      # profiling run (flash_attn.py:630-632)
+                return output.fill_(0)
+            slopes = self.alibi_slopes
+            if slopes is not None and slopes.device != query.device:
+                slopes = self.alibi_slopes = slopes.to(query.device)
+            q3 = query.view(-1, self.num_heads, self.head_size)
+            k3 = key.view(-1, self.num_kv_heads, self.head_size) if key is not None else None
+            v3 = value.view(-1, self.num_kv_heads, self.head_size) if value is not None else None
+            paged_attention_forward(q3, k3, v3, kv_cache, attn_metadata,
+                                    output.view(-1, self.num_heads, self.head_size),
+                                    self.num_kv_heads, self.scale, slopes)
+            return output
+
+    class Mi355xPagedAttentionBackend(AttentionBackend):
+        accept_output_buffer: bool = True
+
+        @classmethod
+        def get_supported_dtypes(cls):
+            return [torch.float16, torch.bfloat16, torch.float32]
+
+        @staticmethod
+        def get_supported_head_sizes():
+            return [32, 64, 80, 96, 112, 120, 128, 192, 256]   # paged_attention_v1.cu:90-124
+
+        @staticmethod
+        def get_name() -> str:
+            return "MI355X_PAGED_ATTN"
+
+        @staticmethod
+        def get_impl_cls():
+            return Mi355xPagedAttentionImpl
+
+        @staticmethod
+        def get_metadata_cls():
+            return Mi355xPagedMetadata
+
+        @staticmethod
+        def get_builder_cls():
+            return Mi355xPagedMetadataBuilder
+
+        @staticmethod
+        def get_kv_cache_shape(num_blocks, block_size, num_kv_heads, head_size,
+                               cache_dtype_str: str = "auto"):
+            if block_size not in (8, 16, 32):
+                raise ValueError("Block size must be 8, 16 or 32.")
+            return kv_cache_shape(num_blocks, block_size, num_kv_heads, head_size)
+
+        @staticmethod
+        def use_cascade_attention(*args, **kwargs) -> bool:
+            return False                                    # platform.py:219-221
+except Exception:  # noqa: BLE001 - vLLM absent: only the core above is available
+    pass

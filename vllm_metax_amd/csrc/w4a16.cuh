@@ -33,20 +33,39 @@ struct Mfma<f16_t> {
   }
 };
 
+// byte -> float conversions: hipcc only pattern-matches v_cvt_f32_ubyte0 and builds the other
+// three out of shift / bfe / and (3 VALU ops instead of 1), so they are spelled out.
+__device__ __forceinline__ float cvt_ubyte0(uint32_t x) { return (float)(x & 0xFFu); }
+__device__ __forceinline__ float cvt_ubyte1(uint32_t x) {
+  float r;
+  asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float cvt_ubyte2(uint32_t x) {
+  float r;
+  asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ float cvt_ubyte3(uint32_t x) {
+  float r;
+  asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 // Dequantise one shuffled word (8 consecutive k of one column) into an MFMA B fragment:
 // value_j = fma(float(q_j), s, zs) with zs = -z*s, rounded to T, natural k order.
 template <typename T>
 __device__ __forceinline__ uint4 dequant_word(uint32_t w, float s, float zs) {
   const uint32_t t0 = w & 0x0F0F0F0Fu;         // bytes: k0, k4, k1, k5
   const uint32_t t1 = (w >> 4) & 0x0F0F0F0Fu;  // bytes: k2, k6, k3, k7
-  const float k0 = (float)((t0 >> 0) & 0xFFu);
-  const float k4 = (float)((t0 >> 8) & 0xFFu);
-  const float k1 = (float)((t0 >> 16) & 0xFFu);
-  const float k5 = (float)((t0 >> 24) & 0xFFu);
-  const float k2 = (float)((t1 >> 0) & 0xFFu);
-  const float k6 = (float)((t1 >> 8) & 0xFFu);
-  const float k3 = (float)((t1 >> 16) & 0xFFu);
-  const float k7 = (float)((t1 >> 24) & 0xFFu);
+  const float k0 = cvt_ubyte0(t0);
+  const float k4 = cvt_ubyte1(t0);
+  const float k1 = cvt_ubyte2(t0);
+  const float k5 = cvt_ubyte3(t0);
+  const float k2 = cvt_ubyte0(t1);
+  const float k6 = cvt_ubyte1(t1);
+  const float k3 = cvt_ubyte2(t1);
+  const float k7 = cvt_ubyte3(t1);
   uint4 r;
   r.x = Mfma<T>::pack(fmaf(k0, s, zs), fmaf(k1, s, zs));
   r.y = Mfma<T>::pack(fmaf(k2, s, zs), fmaf(k3, s, zs));

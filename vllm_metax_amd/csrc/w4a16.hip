@@ -151,24 +151,28 @@ __global__ void permute_cols_kernel(T* __restrict__ out, const T* __restrict__ i
 }
 
 // ------------------------------------------------------------------ small-M kernel
-// C[M<=64, N] tile 64 x 64 per workgroup; the 4 waves split the K range of the workgroup
-// (k-step = 32, interleaved) and are summed through LDS; blockIdx.y splits K across
-// workgroups (fp32 atomics into `acc_ws` when gridDim.y > 1).  HBM-bound regime: weights
-// are read exactly once, A (<= 64 rows, L2 resident) is read as MFMA-shaped fragments.
+// C[M<=64, N] tile 64 x 64 per workgroup of 8 waves; the waves split the K range of the
+// workgroup (k-step = 32, interleaved) and are summed through LDS (tree); blockIdx.y splits
+// K across workgroups (fp32 atomics into `acc_ws` when gridDim.y > 1).
+// Regime: weights are read exactly once (HBM-bound), the kernel is otherwise limited by the
+// dequant VALU work and by memory latency, so it runs 8 waves x 2 workgroups per CU
+// (<= 128 VGPRs) and lets wave-level parallelism hide the latency; weights are prefetched
+// one k-step ahead (7 VGPRs), activations (<= 64 rows, L2 resident) are loaded per step.
 constexpr int kSmBN = 64;
-constexpr int kSmThreads = 256;
+constexpr int kSmWaves = 8;
+constexpr int kSmThreads = kSmWaves * 64;
 
-template <typename T, int MT, int ZMODE>
-__global__ __launch_bounds__(kSmThreads, 3) void w4a16_gemm_small_m_kernel(
+template <typename T, int MT, int ZMODE, bool GPOW2>
+__global__ __launch_bounds__(kSmThreads, 4) void w4a16_gemm_small_m_kernel(
     T* __restrict__ c, float* __restrict__ acc_ws, const T* __restrict__ a,
     const uint32_t* __restrict__ qw, const T* __restrict__ scales,
-    const uint32_t* __restrict__ qz, int m, int n, int k, int group, int64_t lda,
-    int ksteps_per_split) {
+    const uint32_t* __restrict__ qz, int m, int n, int k, int group, int group_shift,
+    int64_t lda, int ksteps_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);  // [2][MT*16][64] fp32
+  float* red = reinterpret_cast<float*>(smem);  // [4][MT*16][64] fp32
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: uniform branches
   const int lc = lane & 15;
   const int lr = lane >> 4;
   const int n0 = blockIdx.x * kSmBN;
@@ -185,64 +189,83 @@ __global__ __launch_bounds__(kSmThreads, 3) void w4a16_gemm_small_m_kernel(
     for (int t = 0; t < 4; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  // A fragment row pointers (rows past M are clamped; their results are never stored)
+  // Activation loads are COALESCED, not MFMA-shaped: lane l reads row 16*i + l/4, 16-byte
+  // chunk l%4 of the k-step (4 consecutive lanes = 64 contiguous bytes).  The MFMA A operand
+  // wants lane (lr, lc) = row lc, chunk lr, i.e. the value held by lane 4*lc + lr: a fixed lane
+  // transpose done with ds_bpermute (LDS crossbar, no LDS memory).  Loading fragment-shaped
+  // (16 different rows per 16 consecutive lanes) made the texture-address unit the bottleneck
+  // (64 cache lines per wave-instruction instead of 8-16).
   const T* arow[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    int r = i * 16 + lc;
+    int r = i * 16 + (lane >> 2);
     r = r < m ? r : m - 1;
-    arow[i] = a + (int64_t)r * lda + 8 * lr;
+    arow[i] = a + (int64_t)r * lda + 8 * (lane & 3);
   }
+  const int perm_addr = (4 * lc + lr) * 4;  // ds_bpermute byte address of the source lane
   const int n8 = n >> 3;
 
-  // Software pipeline, depth 2: the loads of k-step s+4 (this wave's next step) are issued
-  // before the dequant + MFMA work of step s, so HBM / L2 latency hides under compute.
-  struct Stage {
-    uint4 b;        // 4 shuffled words: columns ncol..ncol+3, k-rows 8*(4s+lr)..+7
-    uint4 a[MT];    // A fragments of the MT row tiles
-    uint2 sc;       // 4 scales (scalar_t) of this step's group
-    uint32_t zw;    // packed zero points word
-  };
-  auto load_stage = [&](Stage& st, int s) {
+  uint4 bq[2];
+  uint2 scq[2];
+  uint32_t zq[2];
+  auto load_b = [&](int slot, int s) {
     const int kbase = s * 32;
-    const int g = kbase / group;
-    st.b = *reinterpret_cast<const uint4*>(qw + (int64_t)(4 * s + lr) * n + ncol);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) st.a[i] = *reinterpret_cast<const uint4*>(arow[i] + kbase);
-    st.sc = *reinterpret_cast<const uint2*>(scales + (int64_t)g * n + ncol);
-    st.zw = qz[(int64_t)g * n8 + (ncol >> 3)];
+    const int g = GPOW2 ? (kbase >> group_shift) : (kbase / group);
+    bq[slot] = *reinterpret_cast<const uint4*>(qw + (int64_t)(4 * s + lr) * n + ncol);
+    scq[slot] = *reinterpret_cast<const uint2*>(scales + (int64_t)g * n + ncol);
+    zq[slot] = qz[(int64_t)g * n8 + (ncol >> 3)];
   };
-  auto compute_stage = [&](const Stage& st) {
+  auto compute = [&](int slot, int s) {
+    uint4 af[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(arow[i] + s * 32);
+      af[i].x = __builtin_amdgcn_ds_bpermute(perm_addr, raw.x);
+      af[i].y = __builtin_amdgcn_ds_bpermute(perm_addr, raw.y);
+      af[i].z = __builtin_amdgcn_ds_bpermute(perm_addr, raw.z);
+      af[i].w = __builtin_amdgcn_ds_bpermute(perm_addr, raw.w);
+    }
     T sct[4];
-    *reinterpret_cast<uint2*>(sct) = st.sc;
+    *reinterpret_cast<uint2*>(sct) = scq[slot];
     float zp[4];
-    unpack_zeros4<ZMODE>(st.zw, ncol, zp);
-    const uint32_t words[4] = {st.b.x, st.b.y, st.b.z, st.b.w};
+    unpack_zeros4<ZMODE>(zq[slot], ncol, zp);
+    const uint32_t words[4] = {bq[slot].x, bq[slot].y, bq[slot].z, bq[slot].w};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const float sc = to_f32(sct[t]);
       const uint4 bf = dequant_word<T>(words[t], sc, -zp[t] * sc);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][t] = Mfma<T>::run(st.a[i], bf, acc[i][t]);
+      for (int i = 0; i < MT; ++i) acc[i][t] = Mfma<T>::run(af[i], bf, acc[i][t]);
     }
   };
   {
-    Stage s0, s1;
-    int s = step_begin + wave;
-    if (s < step_end) load_stage(s0, s);
-    while (s < step_end) {
-      const bool more1 = (s + 4) < step_end;
-      if (more1) load_stage(s1, s + 4);
-      compute_stage(s0);
-      if (!more1) break;
-      const bool more2 = (s + 8) < step_end;
-      if (more2) load_stage(s0, s + 8);
-      compute_stage(s1);
-      s += 8;
+    // Every workgroup starts its K sweep at a different k-step (rotation `rot`): all
+    // workgroups read the SAME activation rows, and sweeping them in lock-step concentrates
+    // the requests on few L2 channels.  fp32 accumulation order changes, rounding points don't.
+    const int cnt = step_end - step_begin;
+    const int nsteps = wave < cnt ? (cnt - wave + kSmWaves - 1) / kSmWaves : 0;
+    const int rot = (int)((blockIdx.x * 37u + blockIdx.y * 11u) % (unsigned)max(cnt, 1));
+    auto step_of = [&](int i) {  // i-th k-step of this wave (clamped to its last one)
+      const int ii = i < nsteps ? i : nsteps - 1;
+      int idx = wave + kSmWaves * ii + rot;
+      idx = idx >= cnt ? idx - cnt : idx;
+      return step_begin + idx;
+    };
+    if (nsteps > 0) {
+      load_b(0, step_of(0));
+      for (int it = 0; it < nsteps; it += 2) {
+        load_b(1, step_of(it + 1));
+        __builtin_amdgcn_sched_barrier(0);  // keep the weight prefetch above the compute
+        compute(0, step_of(it));
+        if (it + 1 >= nsteps) break;
+        load_b(0, step_of(it + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, step_of(it + 1));
+      }
     }
   }
 
-  // ---- sum the 4 waves (tree through LDS): 2,3 -> 0,1 ; 1 -> 0 -------------------
+  // ---- sum the 8 waves: tree through LDS (4 slabs) ------------------------------------
   auto lds_store = [&](float* dst) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -269,14 +292,14 @@ __global__ __launch_bounds__(kSmThreads, 3) void w4a16_gemm_small_m_kernel(
     }
   };
   constexpr int kSlab = MT * 16 * 64;
-  if (wave >= 2) lds_store(red + (wave - 2) * kSlab);
-  __syncthreads();
-  if (wave < 2) lds_add(red + wave * kSlab);
-  __syncthreads();
-  if (wave == 1) lds_store(red);
-  __syncthreads();
+#pragma unroll
+  for (int half = kSmWaves / 2; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) lds_store(red + (wave - half) * kSlab);
+    __syncthreads();
+    if (wave < half) lds_add(red + wave * kSlab);
+    __syncthreads();
+  }
   if (wave != 0) return;
-  lds_add(red);
 
   // ---- epilogue: lane holds, for each (i, j), 4 consecutive columns ncol..ncol+3 ----
 #pragma unroll
@@ -335,15 +358,26 @@ static int launch_small_m(const GemmArgs& g, int row0, int rows) {
   sk = (total_steps + steps_per_split - 1) / steps_per_split;
   float* ws = g.ws;
   const int mt = (rows + 15) / 16;
+  int group_shift = -1;  // log2(group) when group is a power of two (avoids an integer division)
+  if ((g.group & (g.group - 1)) == 0) {
+    group_shift = 0;
+    while ((1 << group_shift) < g.group) ++group_shift;
+  }
   dim3 grid(col_tiles, sk), block(kSmThreads);
-#define LAUNCH_SM(MTV)                                                                      \
-  hipLaunchKernelGGL((w4a16_gemm_small_m_kernel<T, MTV, ZMODE>), grid, block,               \
-                     (size_t)2 * MTV * 16 * 64 * sizeof(float), g.stream, c, ws, a, g.qw,    \
-                     static_cast<const T*>(g.scales), g.qz, rows, g.n, g.k, g.group, g.lda, \
-                     steps_per_split)
+#define LAUNCH_SM2(MTV, P2)                                                                  \
+  hipLaunchKernelGGL((w4a16_gemm_small_m_kernel<T, MTV, ZMODE, P2>), grid, block,            \
+                     (size_t)(kSmWaves / 2) * MTV * 16 * 64 * sizeof(float), g.stream, c, ws, a, g.qw,     \
+                     static_cast<const T*>(g.scales), g.qz, rows, g.n, g.k, g.group,         \
+                     group_shift, g.lda, steps_per_split)
+#define LAUNCH_SM(MTV)                      \
+  do {                                      \
+    if (group_shift >= 0) LAUNCH_SM2(MTV, true); \
+    else LAUNCH_SM2(MTV, false);            \
+  } while (0)
   if (mt <= 1) LAUNCH_SM(1);
   else if (mt <= 2) LAUNCH_SM(2);
   else LAUNCH_SM(4);
+#undef LAUNCH_SM2
 #undef LAUNCH_SM
   int rc = check_launch("w4a16_gemm_small_m");
   if (rc) return rc;

@@ -8,10 +8,10 @@
 //   * each of the 4 waves owns 64 columns and ALL 128 rows, so every int4 word is
 //     dequantised exactly once per workgroup; its B operand comes straight from global
 //     memory into VGPRs (one 16-B load per lane and 32-deep k-step, see w4a16.hip);
-//   * the A tile (shared by the 4 waves) is staged through LDS in FRAGMENT-MAJOR order:
-//     piece (mt, ks) is the 1 KiB image of the 16x32 MFMA A operand, lane l at byte 16*l,
-//     so the ds_read_b128 of a fragment is lane-linear (conflict-free) — the shuffle is
-//     done once by the global->LDS staging pass (issue-early / write-late, double buffer);
+//   * the A tile (shared by the 4 waves) is read from global memory in full 128-byte lines
+//     (8 lanes per row) and staged through LDS in FRAGMENT-MAJOR order: piece (mt, ks) is
+//     the 1 KiB image of one 16x32 MFMA A operand, so a fragment is one ds_read_b128 per
+//     lane (issue-early / write-late double buffering);
 //   * blockIdx is remapped so that the workgroups resident on one XCD share a B panel.
 #include "w4a16.cuh"
 
@@ -52,15 +52,23 @@ __global__ __launch_bounds__(kLgThreads, 2) void w4a16_gemm_large_m_kernel(
   const int n8 = n >> 3;
   const int ktiles = k / kLgBK;
 
-  // A staging assignment: wave w stages pieces 4w .. 4w+3; piece p = (mt = p>>1, ks = p&1)
+  // A staging: COALESCED global loads — thread t reads row t/8 (+32 per pass), 16-byte chunk
+  // t%8 of the row's 128-byte K-tile segment (8 consecutive lanes = one full 128-B line) — and
+  // writes it to the fragment-major LDS image: piece (mt = row/16, ks = chunk/4), slot
+  // (row%16)*4 + chunk%4, so that the MFMA A fragment of lane (lr, lc) is slot lc*4 + lr.
+  const int st_row = threadIdx.x >> 3;   // 0..31
+  const int st_chunk = threadIdx.x & 7;  // 0..7
   const T* a_src[4];
+  int a_dst[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int p = wave * 4 + i;
-    int row = mb * kLgBM + (p >> 1) * 16 + lc;
+    const int lrow = st_row + 32 * i;    // row inside the 128-row tile
+    int row = mb * kLgBM + lrow;
     row = row < m ? row : m - 1;
-    a_src[i] = a + (int64_t)row * lda + (p & 1) * 32 + 8 * lr;
+    a_src[i] = a + (int64_t)row * lda + 8 * st_chunk;
+    a_dst[i] = ((lrow >> 4) * 2 + (st_chunk >> 2)) * 64 + (lrow & 15) * 4 + (st_chunk & 3);
   }
+  const int frag_slot = lc * 4 + lr;
 
   f32x4_t acc[kLgMT][4];
 #pragma unroll
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(kLgThreads, 2) void w4a16_gemm_large_m_kernel(
   };
   auto store_a = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a_lds[(buf * 16 + wave * 4 + i) * 64 + lane] = a_stage[i];
+    for (int i = 0; i < 4; ++i) a_lds[buf * 1024 + a_dst[i]] = a_stage[i];
   };
   auto load_b = [&](int kt, uint4 (&dst)[2]) {
     if (wave_active) {
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(kLgThreads, 2) void w4a16_gemm_large_m_kernel(
         for (int t = 0; t < 4; ++t) bf[t] = dequant_word<T>(words[t], sc[t], -zp[t] * sc[t]);
 #pragma unroll
         for (int i = 0; i < kLgMT; ++i) {
-          const uint4 af = a_lds[(cur * 16 + i * 2 + ks) * 64 + lane];
+          const uint4 af = a_lds[(cur * 16 + i * 2 + ks) * 64 + frag_slot];
 #pragma unroll
           for (int t = 0; t < 4; ++t) acc[i][t] = Mfma<T>::run(af, bf[t], acc[i][t]);
         }

@@ -1,0 +1,86 @@
+"""vLLM-independent core of the AWQ / GPTQ linear methods (the code the vLLM-facing classes in
+awq.py / gptq.py delegate to), so that it can be exercised without upstream vLLM.
+
+ref: vllm_metax/quant_config/awq.py:69-80 (process_weights_after_loading), :118-159
+(_apply_awq); vllm_metax/quant_config/gptq.py:49-129, :180-229 (_apply_gptq)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _custom_ops as ops
+
+
+def awq_process_weights(qweight: torch.Tensor, group_size: int) -> torch.Tensor:
+    """AWQ -> exllama repack, once after loading (awq.py:72-80).  group_size % 32 != 0 keeps
+    the original layout (served by awq_dequantize + matmul, as in the reference)."""
+    if group_size % 32:
+        return qweight
+    return ops.awq_to_gptq_4bit(qweight)
+
+
+def apply_awq(x: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor,
+              bias: Optional[torch.Tensor], pack_factor: int, group_size: int) -> torch.Tensor:
+    """ref: awq.py:118-159."""
+    reshaped_x = x.reshape(-1, x.shape[-1])
+    if group_size % 32:
+        out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor,)
+        w = ops.awq_dequantize(qweight, scales, qzeros, 0, 0, 0)
+        out = torch.matmul(reshaped_x, w)
+    else:
+        n = qweight.shape[0]                      # declared [N, K/8]
+        out_shape = x.shape[:-1] + (n,)
+        temp_space = torch.empty(0, dtype=torch.float32, device=x.device)
+        if reshaped_x.shape[0] <= 64:             # split-K workspace only matters for decode
+            temp_space = torch.zeros(reshaped_x.shape[0], n, dtype=torch.float32, device=x.device)
+        out = ops.awq_gemm(reshaped_x, qweight, qzeros, scales, pack_factor, temp_space,
+                           reshaped_x.dtype == torch.bfloat16)
+    if bias is not None:
+        out.add_(bias)
+    return out.reshape(out_shape)
+
+
+def apply_awq_fake(x, qweight, scales, qzeros, bias, pack_factor, group_size):
+    """ref: awq.py:101-115 (fake impl for torch.compile)."""
+    n = qweight.shape[-1] * pack_factor if group_size % 32 else qweight.shape[0]
+    return torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
+
+
+def gptq_process_weights(qweight: torch.Tensor, g_idx: torch.Tensor, desc_act: bool,
+                         weight_bits: int) -> torch.Tensor:
+    """ref: gptq.py:49-75 — argsort g_idx when act-order, then exllama shuffle in place.
+    Returns the g_idx to keep on the layer (argsort permutation or empty)."""
+    if desc_act:
+        g_idx = torch.argsort(g_idx).to(torch.int)
+    else:
+        g_idx = torch.empty((0,), dtype=torch.int, device=g_idx.device)
+    ops.gptq_shuffle(qweight, g_idx, weight_bits)
+    return g_idx
+
+
+def apply_gptq(x: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor,
+               bias: Optional[torch.Tensor], g_idx: torch.Tensor, use_exllama: bool,
+               weight_bits: int, group_size: int, desc_act: bool) -> torch.Tensor:
+    """ref: gptq.py:180-229."""
+    reshaped_x = x.reshape(-1, x.shape[-1])
+    out_shape = x.shape[:-1] + (qweight.shape[-1],)
+    perm_space = torch.empty(0)
+    temp_space = torch.empty(0)
+    if desc_act:
+        perm_space = torch.empty(reshaped_x.shape[0], reshaped_x.shape[1], dtype=torch.float16,
+                                 device=x.device)
+    if reshaped_x.shape[0] <= 64:
+        temp_space = torch.zeros(reshaped_x.shape[0], qweight.shape[1], dtype=torch.float32,
+                                 device=x.device)
+    out = ops.gptq_gemm(reshaped_x, qweight, qzeros, scales, g_idx, use_exllama, weight_bits,
+                        group_size, perm_space, temp_space, reshaped_x.dtype == torch.bfloat16)
+    if bias is not None:
+        out.add_(bias)
+    return out.reshape(out_shape)
+
+
+def apply_gptq_fake(x, qweight, scales, qzeros, bias, g_idx, use_exllama, weight_bits, group_size,
+                    desc_act):
+    """ref: gptq.py:164-177."""
+    return torch.empty(x.shape[:-1] + (qweight.shape[-1],), dtype=x.dtype, device=x.device)
