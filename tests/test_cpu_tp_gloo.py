@@ -1,0 +1,137 @@
+"""CPU, world_size 2 over gloo: the tensor-parallel decomposition used by bench.py --gpus N
+(one process per GPU; heads / FFN sharded; all-reduce after the row-parallel o_proj and
+down_proj; all-gather of the vocab-parallel logits) reproduces the unsharded layer.
+
+The layer arithmetic here is the CPU oracle (the HIP ops need a GPU); what is under test is the
+sharding / collective structure of vllm_metax_amd/harness.py: which slices each
+rank owns and where the collectives sit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_ops as R
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_weights(seed, h, heads, kv_heads, d, ffn, group):
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(k, n):
+        w = rng.integers(0, 16, size=(k, n), dtype=np.uint8)
+        z = rng.integers(0, 16, size=(k // group, n), dtype=np.uint8)
+        s = (torch.rand(k // group, n, generator=g) * 4e-3 + 1e-3).to(torch.bfloat16)
+        return w, z, s
+    return {"q": lin(h, heads * d), "k": lin(h, kv_heads * d), "v": lin(h, kv_heads * d),
+            "o": lin(heads * d, h), "gate": lin(h, ffn), "up": lin(h, ffn), "down": lin(ffn, h)}
+
+
+def _gemm(x, wzs, cols=None, rows=None, group=32):
+    """x @ dequant(w) with optional column slice (column-parallel) or row slice (row-parallel)."""
+    w, z, s = wzs
+    if cols is not None:
+        w, z, s = w[:, cols], z[:, cols], s[:, cols]
+    if rows is not None:
+        w = w[rows]
+        z = z[rows.start // group:rows.stop // group]
+        s = s[rows.start // group:rows.stop // group]
+    wd = R.w4_dequant(w, z, s, group)
+    return (x.double() @ wd.double()).to(x.dtype)
+
+
+def _layer(x, W, heads, kv_heads, d, ffn, rank, tp, group, reduce_fn):
+    """One decoder layer's linear path (attention replaced by a per-head identity mix, which is
+    head-local like the real attention): returns the layer output on every rank."""
+    hq, hkv, f = heads // tp, kv_heads // tp, ffn // tp
+    qs = slice(rank * hq * d, (rank + 1) * hq * d)
+    ks = slice(rank * hkv * d, (rank + 1) * hkv * d)
+    fs = slice(rank * f, (rank + 1) * f)
+    q = _gemm(x, W["q"], cols=qs, group=group)
+    k = _gemm(x, W["k"], cols=ks, group=group)
+    v = _gemm(x, W["v"], cols=ks, group=group)
+    G = heads // kv_heads
+    attn = (q.view(-1, hq, d).float() * 0.5 + k.view(-1, hkv, d).repeat_interleave(G, 1).float() * 0.25
+            + v.view(-1, hkv, d).repeat_interleave(G, 1).float() * 0.25).to(x.dtype).reshape(-1, hq * d)
+    o = reduce_fn(_gemm(attn, W["o"], rows=qs, group=group).float()).to(x.dtype)   # row-parallel
+    gate = _gemm(o, W["gate"], cols=fs, group=group)
+    up = _gemm(o, W["up"], cols=fs, group=group)
+    act = R.silu_and_mul(torch.cat([gate, up], dim=-1))
+    return reduce_fn(_gemm(act, W["down"], rows=fs, group=group).float()).to(x.dtype)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    h, heads, kv_heads, d, ffn, group = 128, 4, 2, 32, 256, 32
+    W = _make_weights(0, h, heads, kv_heads, d, ffn, group)
+    x = (torch.randn(6, h, generator=torch.Generator().manual_seed(1)) * 0.5).to(torch.bfloat16)
+
+    def allreduce(t):
+        dist.all_reduce(t)
+        return t
+    out = _layer(x, W, heads, kv_heads, d, ffn, rank, world, group, allreduce)
+    # vocab-parallel logits + all-gather (harness._logits_argmax)
+    vocab = 64
+    lm = (torch.randn(h, vocab, generator=torch.Generator().manual_seed(2)) * 0.02).to(torch.bfloat16)
+    shard = lm[:, rank * vocab // world:(rank + 1) * vocab // world]
+    part = torch.matmul(out.float(), shard.float())
+    parts = [torch.empty_like(part) for _ in range(world)]
+    dist.all_gather(parts, part)
+    tok = torch.cat(parts, dim=-1).argmax(-1)
+    if rank == 0:
+        q.put((out.float().numpy(), tok.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_tp2_matches_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out_tp, tok_tp = q.get(timeout=150)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    h, heads, kv_heads, d, ffn, group = 128, 4, 2, 32, 256, 32
+    W = _make_weights(0, h, heads, kv_heads, d, ffn, group)
+    x = (torch.randn(6, h, generator=torch.Generator().manual_seed(1)) * 0.5).to(torch.bfloat16)
+    ref = _layer(x, W, heads, kv_heads, d, ffn, 0, 1, group, lambda t: t)
+    lm = (torch.randn(h, 64, generator=torch.Generator().manual_seed(2)) * 0.02).to(torch.bfloat16)
+    tok_ref = torch.matmul(ref.float(), lm.float()).argmax(-1)
+    # partial sums are rounded to bf16 once after the fp32 all-reduce: within 1 bf16 ulp
+    err = np.abs(out_tp - ref.float().numpy()).max()
+    assert err <= 2.0 ** -7 * np.abs(ref.float().numpy()).max() * 1.01, err
+    assert np.array_equal(tok_tp, tok_ref.numpy())
+
+
+def test_harness_shard_sizes():
+    """Per-rank shapes of the harness layers match BASELINE.md §3 (Qwen2-72B / Llama-70B TP=8)."""
+    from vllm_metax_amd import harness
+    c = harness.ModelConfig.qwen2_72b("gptq", tp=8)
+    hq, hkv, ffn = c.heads // c.tp, max(c.kv_heads // c.tp, 1), c.ffn // c.tp
+    assert (c.hidden, (hq + 2 * hkv) * c.head_dim) == (8192, 1280)
+    assert (hq * c.head_dim, c.hidden) == (1024, 8192)
+    assert (c.hidden, 2 * ffn) == (8192, 7424) and (ffn, c.hidden) == (3712, 8192)
+    c = harness.ModelConfig.llama3_70b("fp8", tp=8)
+    assert (c.hidden, 2 * (c.ffn // 8)) == (8192, 7168) and (c.ffn // 8) == 3584
+    for tp in (1, 2, 4, 8):            # the bench's TP=N shards of Llama-3-8B stay group-aligned
+        c = harness.ModelConfig.llama3_8b("awq", tp=tp)
+        assert (c.heads // tp) * c.head_dim % c.group_size == 0
+        assert (c.ffn // tp) % c.group_size == 0
