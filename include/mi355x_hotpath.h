@@ -224,8 +224,9 @@ int mi355x_awq_dequantize(void* out, const uint32_t* qweight, const void* scales
 
 /* awq_gemm: C[M,N] = A[M,K] . ((Q - Z) * S); Q in the exllama layout produced by
  * awq_to_gptq_4bit, qzeros [K/g, N/8] in AWQ nibble order, scales [K/g, N].
- * `workspace` (float, >= m*n when the kernel chooses split-K, may be NULL
- * otherwise) is the reference's temp_space; it is zero-filled by the call.
+ * `workspace` (float, >= m*n, may be NULL: then K is never split across workgroups) is the
+ * reference's temp_space and, like it (awq.py:140-147: a fresh torch.zeros), MUST be all zero
+ * on entry; the call hands it back all zero, so one buffer can be reused without a memset.
  * ref: csrc/quantization/awq/gemm_kernels.cu:410-463, :283-318, :186-281. */
 int mi355x_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* scales,
                     const uint32_t* qzeros, float* workspace, int64_t workspace_elems,

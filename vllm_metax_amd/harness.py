@@ -93,7 +93,8 @@ class QLinear:
     def _workspace(self, m: int, device):
         ws = self._ws.get(m)
         if ws is None:
-            ws = torch.empty(m, self.n, dtype=torch.float32, device=device)
+            # zero on entry (the reference's temp_space contract); the GEMM hands it back zeroed
+            ws = torch.zeros(m, self.n, dtype=torch.float32, device=device)
             self._ws[m] = ws
         return ws
 
