@@ -227,11 +227,15 @@ int mi355x_awq_dequantize(void* out, const uint32_t* qweight, const void* scales
  * `workspace` (float, >= m*n, may be NULL: then K is never split across workgroups) is the
  * reference's temp_space and, like it (awq.py:140-147: a fresh torch.zeros), MUST be all zero
  * on entry; the call hands it back all zero, so one buffer can be reused without a memset.
+ * `dq_workspace` (>= (n + roundup(m,16))*k*2 bytes, may be NULL) is scratch for prefill-sized
+ * M (>= 1024): weights are dequantised once and activations re-tiled into MFMA operand images
+ * in it, then a pure-MFMA GEMM follows (same numerics); without it the fused dequant-GEMM
+ * kernel is used for every M.  Contents on exit are unspecified.
  * ref: csrc/quantization/awq/gemm_kernels.cu:410-463, :283-318, :186-281. */
 int mi355x_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* scales,
                     const uint32_t* qzeros, float* workspace, int64_t workspace_elems,
-                    int m, int n, int k, int group_size, int64_t lda, int dtype,
-                    mi355x_stream stream);
+                    void* dq_workspace, int64_t dq_workspace_bytes, int m, int n, int k,
+                    int group_size, int64_t lda, int dtype, mi355x_stream stream);
 
 /* gptq_shuffle: in-place exllama nibble shuffle of q_weight [K/8, N]; with q_perm
  * (int32 [K]) rows are first made sequential through `scratch` (>= K/8*N words).
@@ -246,9 +250,9 @@ int mi355x_gptq_shuffle(uint32_t* q_weight, const int* q_perm, uint32_t* scratch
  * ref: csrc/quantization/gptq/q_gemm.cu:2373-2413, :1983-2007, :1770-1786. */
 int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,
                      const uint32_t* qzeros, const void* scales, const int* g_idx,
-                     void* perm_space, float* workspace, int64_t workspace_elems, int m,
-                     int n, int k, int bit, int group_size, int dtype,
-                     mi355x_stream stream);
+                     void* perm_space, float* workspace, int64_t workspace_elems,
+                     void* dq_workspace, int64_t dq_workspace_bytes, int m, int n, int k, int bit,
+                     int group_size, int dtype, mi355x_stream stream);
 
 /* ----------------------------------------------------------------- fp8 GEMM --
  * out[M,N] (bf16/f16) = (a_scales . a[M,K] e4m3fn row-major) x

@@ -52,9 +52,9 @@ def test_argument_errors_surface_without_a_gpu(built):
     rc = lib.mi355x_paged_attention_v1(None, None, None, None, 4, 32, 8, 72, 16, 1.0, None, None,
                                        4, 64, None, 0, 0, 0, built.BF16, None)
     assert rc == -2 and "Unsupported head size" in built.last_error()
-    rc = lib.mi355x_awq_gemm(None, None, None, None, None, None, 0, 4, 100, 512, 128, 512, built.BF16, None)
+    rc = lib.mi355x_awq_gemm(None, None, None, None, None, None, 0, None, 0, 4, 100, 512, 128, 512, built.BF16, None)
     assert rc == -2 and "multiple of 64" in built.last_error()
-    rc = lib.mi355x_gptq_gemm(None, None, None, None, None, None, None, None, 0, 4, 128, 512, 3, 128,
+    rc = lib.mi355x_gptq_gemm(None, None, None, None, None, None, None, None, 0, None, 0, 4, 128, 512, 3, 128,
                               built.BF16, None)
     assert rc == -2 and "4-bit" in built.last_error()
     rc = lib.mi355x_rms_norm(None, None, None, 1e-5, 0, 4096, 4096, built.BF16, None)

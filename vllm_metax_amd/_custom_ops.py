@@ -407,6 +407,22 @@ def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
 
 
 # ----------------------------------------------------------------- int4 weight-only
+_DQ_SCRATCH: dict = {}
+
+
+def _dq_scratch(m: int, n: int, k: int, device) -> Optional[torch.Tensor]:
+    """Scratch for the dequantised weights of a prefill-sized GEMM (one buffer per device,
+    grown to the largest n*k seen; the kernels of one stream run in order, so sharing is safe)."""
+    if m < 1024:
+        return None
+    need = (n + (m + 15) // 16 * 16) * k * 2    # packed weights + packed activations
+    buf = _DQ_SCRATCH.get(device)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device=device)
+        _DQ_SCRATCH[device] = buf
+    return buf
+
+
 def awq_to_gptq_4bit(qweight: torch.Tensor) -> torch.Tensor:
     """ref: vllm_metax/_custom_ops.py:26-29; csrc/quantization/awq/gemm_kernels.cu:323-356.
     Returns a tensor DECLARED [N, K/8] whose memory is [K/8, N] (the reference's quirk)."""
@@ -448,8 +464,10 @@ def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
     out = torch.empty((m, n), dtype=input.dtype, device=input.device)
     ws = temp_space if (temp_space is not None and temp_space.is_cuda
                         and temp_space.dtype == torch.float32 and temp_space.numel() > 0) else None
+    dq = _dq_scratch(m, n, k, input.device)
     rc = _abi.load().mi355x_awq_gemm(_ptr(out), _ptr(input), _ptr(qweight), _ptr(scales),
                                      _ptr(qzeros), _ptr(ws), ws.numel() if ws is not None else 0,
+                                     _ptr(dq), dq.numel() if dq is not None else 0,
                                      m, n, k, group, input.stride(0), _dt(input), _stream())
     _abi.check(rc, "awq_gemm")
     return out
@@ -497,9 +515,11 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Te
     ws = temp_space if (temp_space is not None and temp_space.is_cuda
                         and temp_space.dtype == torch.float32 and temp_space.numel() > 0) else None
     out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    dq = _dq_scratch(m, n, k, a.device)
     rc = _abi.load().mi355x_gptq_gemm(_ptr(out), _ptr(a), _ptr(b_q_weight), _ptr(b_gptq_qzeros),
                                       _ptr(b_gptq_scales), _ptr(g_idx), _ptr(pspace), _ptr(ws),
-                                      ws.numel() if ws is not None else 0, m, n, k, bit,
+                                      ws.numel() if ws is not None else 0, _ptr(dq),
+                                      dq.numel() if dq is not None else 0, m, n, k, bit,
                                       group_size, _dt(a), _stream())
     _abi.check(rc, "gptq_gemm")
     return out

@@ -259,10 +259,13 @@ Tensor awq_gemm(Tensor in_feats, Tensor kernel, Tensor scaling_factors, Tensor z
     ws = temp_space.data_ptr<float>();
     ws_elems = temp_space.numel();
   }
+  Tensor dq;  // scratch for the dequantised weights of prefill-sized GEMMs
+  if (m >= 1024) dq = at::empty({(n + (m + 15) / 16 * 16) * k * 2}, in_feats.options().dtype(at::kByte));
   ok(mi355x_awq_gemm(out.data_ptr(), in_feats.data_ptr(),
                      static_cast<const uint32_t*>(kernel.data_ptr()), scaling_factors.data_ptr(),
-                     static_cast<const uint32_t*>(zeros.data_ptr()), ws, ws_elems, m, n, k, group,
-                     in_feats.stride(0), dt(in_feats), stream_of(in_feats)),
+                     static_cast<const uint32_t*>(zeros.data_ptr()), ws, ws_elems,
+                     dq.defined() ? dq.data_ptr() : nullptr, dq.defined() ? dq.numel() : 0, m, n, k,
+                     group, in_feats.stride(0), dt(in_feats), stream_of(in_feats)),
      "awq_gemm");
   return out;
 }
@@ -308,12 +311,15 @@ Tensor gptq_gemm(Tensor a, Tensor b_q_weight, Tensor b_gptq_qzeros, Tensor b_gpt
     ws = temp_space.data_ptr<float>();
     ws_elems = temp_space.numel();
   }
+  Tensor dq;
+  if (m >= 1024) dq = at::empty({(n + (m + 15) / 16 * 16) * k * 2}, a.options().dtype(at::kByte));
   ok(mi355x_gptq_gemm(out.data_ptr(), a.data_ptr(),
                       static_cast<const uint32_t*>(b_q_weight.data_ptr()),
                       static_cast<const uint32_t*>(b_gptq_qzeros.data_ptr()),
                       b_gptq_scales.data_ptr(), has_idx ? idx.data_ptr<int>() : nullptr,
-                      has_idx ? pspace.data_ptr() : nullptr, ws, ws_elems, m, n, k, bit,
-                      group_size, dt(a), stream_of(a)),
+                      has_idx ? pspace.data_ptr() : nullptr, ws, ws_elems,
+                      dq.defined() ? dq.data_ptr() : nullptr, dq.defined() ? dq.numel() : 0, m, n,
+                      k, bit, group_size, dt(a), stream_of(a)),
      "gptq_gemm");
   return out;
 }

@@ -104,6 +104,8 @@ struct GemmArgs {
   const uint32_t* qz;
   float* ws;
   int64_t ws_elems;
+  void* dq_ws;           // optional scratch for the dequantised weights (unfused prefill path)
+  int64_t dq_ws_bytes;
   int m, n, k, group;
   int64_t lda;
   int zmode;

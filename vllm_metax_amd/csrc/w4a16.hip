@@ -340,6 +340,7 @@ __global__ void f32_to_t_kernel(T* __restrict__ out, float* __restrict__ in, int
 }
 
 int w4a16_gemm_large_m_dispatch(const GemmArgs& g, int dtype);  // w4a16_large.hip
+int w4a16_gemm_unfused_dispatch(const GemmArgs& g, int dtype);  // w4a16_unfused.hip
 
 template <typename T, int ZMODE>
 static int launch_small_m(const GemmArgs& g, int row0, int rows) {
@@ -392,6 +393,10 @@ static int launch_small_m(const GemmArgs& g, int row0, int rows) {
 
 template <typename T>
 static int run_gemm_t(const GemmArgs& g, int dtype) {
+  if (g.m >= 1024) {
+    int rc = w4a16_gemm_unfused_dispatch(g, dtype);
+    if (rc != 1) return rc;  // 1 = no scratch / shape not handled: fall through to the fused kernel
+  }
   if (g.m >= 128) {
     int rc = w4a16_gemm_large_m_dispatch(g, dtype);
     if (rc != 1) return rc;  // 1 = shape not handled by the large-M kernel
@@ -489,10 +494,11 @@ int mi355x_gptq_shuffle(uint32_t* q_weight, const int* q_perm, uint32_t* scratch
 
 int mi355x_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* scales,
                     const uint32_t* qzeros, float* workspace, int64_t workspace_elems,
-                    int m, int n, int k, int group_size, int64_t lda, int dtype,
-                    mi355x_stream stream) {
-  GemmArgs g{c, a, qweight, scales, qzeros, workspace, workspace_elems, m, n, k, group_size,
-             lda, kZeroAwq, static_cast<hipStream_t>(stream)};
+                    void* dq_workspace, int64_t dq_workspace_bytes, int m, int n, int k,
+                    int group_size, int64_t lda, int dtype, mi355x_stream stream) {
+  GemmArgs g{c, a, qweight, scales, qzeros, workspace, workspace_elems, dq_workspace,
+             dq_workspace_bytes, m, n, k, group_size, lda, kZeroAwq,
+             static_cast<hipStream_t>(stream)};
   int rc = validate_gemm(g, "awq_gemm");
   if (rc || m == 0) return rc;
   return MI355X_DISPATCH_HALF(dtype, [&] { return run_gemm_t<scalar_t>(g, dtype); });
@@ -500,13 +506,14 @@ int mi355x_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void*
 
 int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,
                      const uint32_t* qzeros, const void* scales, const int* g_idx,
-                     void* perm_space, float* workspace, int64_t workspace_elems, int m,
-                     int n, int k, int bit, int group_size, int dtype,
-                     mi355x_stream stream) {
+                     void* perm_space, float* workspace, int64_t workspace_elems,
+                     void* dq_workspace, int64_t dq_workspace_bytes, int m, int n, int k, int bit,
+                     int group_size, int dtype, mi355x_stream stream) {
   MI355X_REQUIRE(bit == 4, MI355X_EUNSUPPORTED,
                  "gptq_gemm: only 4-bit weights are implemented (bit=%d)", bit);
-  GemmArgs g{c, a, qweight, scales, qzeros, workspace, workspace_elems, m, n, k, group_size,
-             k, kZeroGptq, static_cast<hipStream_t>(stream)};
+  GemmArgs g{c, a, qweight, scales, qzeros, workspace, workspace_elems, dq_workspace,
+             dq_workspace_bytes, m, n, k, group_size, k, kZeroGptq,
+             static_cast<hipStream_t>(stream)};
   int rc = validate_gemm(g, "gptq_gemm");
   if (rc || m == 0) return rc;
   if (g_idx) {

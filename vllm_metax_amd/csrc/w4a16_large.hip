@@ -40,8 +40,20 @@ __global__ __launch_bounds__(kLgThreads, 2) void w4a16_gemm_large_m_kernel(
     const int xcd = b % 8;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
   }
-  const int nb = tile / num_m_blocks;
-  const int mb = tile - nb * num_m_blocks;
+  // grouped rasterisation: consecutive tiles sweep 8 row-blocks per column-block, so the ~32
+  // tiles resident on one XCD form an 8 x 4 patch that shares A and B K-slices in its L2
+  // (a 32 x 1 strip re-streams every A panel from HBM/MALL for every column block).
+  int mb, nb;
+  {
+    constexpr int GM = 8;
+    const int num_n_blocks = num_tiles / num_m_blocks;
+    const int group = tile / (GM * num_n_blocks);
+    const int first_m = group * GM;
+    const int gsz = min(num_m_blocks - first_m, GM);
+    const int within = tile - group * GM * num_n_blocks;
+    mb = first_m + within % gsz;
+    nb = within / gsz;
+  }
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;

@@ -1,0 +1,279 @@
+// w4a16_unfused.hip — prefill-sized w4a16 GEMM as two kernels: (1) dequantise the int4 weight
+// matrix ONCE into an MFMA-operand-shaped bf16/f16 workspace, (2) a 256x256x64 MFMA GEMM whose
+// inner loop is pure LDS-read + MFMA (no dequant VALU competing with the matrix pipe).
+//
+// Why: measured on MI355X (profiles/r01_pmc_w4a16_large.txt) the fused kernel issues 4.8 VALU
+// instructions per MFMA (exact dequant costs ~3 VALU ops per weight and is replicated per
+// 128-row tile), so its VALU issue time (30 % of the kernel) exceeds its MFMA time (25 %).
+// Dequantising once costs N*K*2.5 bytes of extra HBM traffic (< 5 % of the GEMM time at
+// M = 8192) and makes the contraction MFMA-bound.  The reference takes the same route for
+// shapes its fused kernel does not cover (awq.py:136-139: awq_dequantize + matmul).
+//
+// Numerics are those of the fused kernels (w4a16.cuh): w = T(fma(q, s, -z*s)) exactly as the
+// reference (hgemm_gptq.h:487-570, 869-905), fp32 MFMA accumulation, one rounding of C.
+//
+// Packed-B workspace layout (produced by kernel 1, consumed by kernel 2): pieces of 1 KiB
+//   P[nt = N/16][kt = K/32][slot 0..63][8 x T]
+// piece (nt, kt) is the LDS image of one 16-column x 32-k MFMA B operand: the 8 consecutive-k
+// values of column-lane lc, k-group lr live at slot swz(lr, lc) = lr*16 + (lc ^ g[lr]),
+// g = {0, 12, 2, 14}.  That XOR makes BOTH the fragment read (lane (lr,lc) -> ds_read_b128,
+// lane groups {0-3,12-15,20-27}, ...) AND the row-major staging write (lane l -> row l/4,
+// chunk l%4 -> ds_write_b128, 8-lane groups) bank-conflict free (derivation in DESIGN.md §3).
+// Column tiles are interleaved inside a 64-column group exactly as in the fused kernel
+// (tile t owns columns 64q + 4c + t), so a lane's 4 accumulators are 4 consecutive columns.
+#include "w4a16.cuh"
+
+namespace mi355x {
+
+__device__ __forceinline__ int frag_swz(int lr, int lc) {
+  // g = {0, 12, 2, 14}[lr]  ==  ((lr & 1) * 12) | ((lr & 2))
+  return lr * 16 + (lc ^ (((lr & 1) * 12) | (lr & 2)));
+}
+
+// ---------------------------------------------------------------- kernel 1: dequant + pack
+// one thread per shuffled word (kk, n): 8 consecutive k of column n -> one 16-byte slot.
+template <typename T, int ZMODE>
+__global__ void w4_dequant_pack_kernel(T* __restrict__ packed, const uint32_t* __restrict__ qw,
+                                       const T* __restrict__ scales,
+                                       const uint32_t* __restrict__ qz, int n, int k, int group) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int k8 = k >> 3;
+  if (idx >= (int64_t)k8 * n) return;
+  const int kk = (int)(idx / n);
+  const int col = (int)(idx - (int64_t)kk * n);
+  const int g = (kk * 8) / group;
+  const uint32_t w = qw[idx];
+  const float s = to_f32(scales[(int64_t)g * n + col]);
+  const uint32_t zw = qz[(int64_t)g * (n >> 3) + (col >> 3)];
+  float z;
+  if constexpr (ZMODE == kZeroAwq) {
+    z = (float)((zw >> (4 * awq_shift(col & 7))) & 0xFu);
+  } else {
+    z = (float)(((zw >> (4 * (col & 7))) & 0xFu) + 1u);
+  }
+  const uint4 v = dequant_word<T>(w, s, -z * s);
+  // destination piece / slot
+  const int q = col >> 6, c = (col & 63) >> 2, t = col & 3;
+  const int nt = q * 4 + t;
+  const int kt = kk >> 2, lr = kk & 3;
+  uint4* dst = reinterpret_cast<uint4*>(packed) + ((int64_t)nt * (k >> 5) + kt) * 64 + frag_swz(lr, c);
+  *dst = v;
+}
+
+// ---------------------------------------------------------------- kernel 2: pack activations
+// A [M, K] row-major -> pieces PA[mt][kt][64 slots x 16 B] in the same swizzled operand image
+// (slot swz(lr, lc) = A[16 mt + lc][32 kt + 8 lr .. +7]); rows >= M are zero.  One workgroup
+// packs 16 rows x 256 k: coalesced 16-B reads (a row's 512 contiguous bytes by 32 lanes), the
+// shuffle happens in LDS, the 8 KiB image is written out linearly.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_a_kernel(T* __restrict__ packed, const T* __restrict__ a,
+                                                     int m, int k, int64_t lda) {
+  __shared__ uint4 img[8 * 64];
+  const int mt = blockIdx.y;
+  const int k0 = blockIdx.x * 256;                 // first k of this block (8 pieces of 32)
+  const int kt32 = k >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256;         // 0..511 : row = idx / 32, chunk = idx % 32
+    const int r = idx >> 5, ch = idx & 31;
+    const int row = mt * 16 + r;
+    const int kk = k0 + ch * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < m && kk < k) v = *reinterpret_cast<const uint4*>(a + (int64_t)row * lda + kk);
+    img[(ch >> 2) * 64 + frag_swz(ch & 3, r)] = v;
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(packed) + ((int64_t)mt * kt32 + (k0 >> 5)) * 64;
+  const int pieces = min(8, kt32 - (k0 >> 5));
+  for (int idx = threadIdx.x; idx < pieces * 64; idx += 256) dst[idx] = img[idx];
+}
+
+// ---------------------------------------------------------------- kernel 3: the GEMM
+// C[M,N] = PA . PB^T with BOTH operands pre-packed as MFMA operand images: every staging
+// transfer is a lane-linear 1 KiB global_load_lds (no VGPR staging, no address shuffles), the
+// inner loop is ds_read_b128 + MFMA only.  256 x 256 x 64 tile, 8 waves (2 x 4), each wave
+// 128 x 64; two 64-KiB LDS stages; the loads of tile t+1 are in flight during the MFMAs of tile t.
+constexpr int kUfBM = 256;
+constexpr int kUfBN = 256;
+constexpr int kUfBK = 64;
+constexpr int kUfThreads = 512;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+
+template <typename T>
+__global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
+    T* __restrict__ c, const uint4* __restrict__ pa, const uint4* __restrict__ pb, int m, int n,
+    int k, int num_m_blocks, int num_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+  // per stage: A pieces [16 mt][2 ks][64] then B pieces [16 nt][2 ks][64]  (uint4 units)
+  constexpr int kStage = 2 * 16 * 2 * 64;  // 4096 uint4 = 64 KiB
+  constexpr int kBOff = 16 * 2 * 64;
+
+  int tile;
+  {
+    const int b = blockIdx.x;
+    const int q = num_tiles / 8, r = num_tiles % 8;
+    const int xcd = b % 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+  }
+  // grouped rasterisation: consecutive tiles sweep 8 row-blocks per column-block, so the ~32
+  // tiles resident on one XCD form an 8 x 4 patch that shares A and B K-slices in its L2
+  // (a 32 x 1 strip re-streams every A panel from HBM/MALL for every column block).
+  int mb, nb;
+  {
+    constexpr int GM = 8;
+    const int num_n_blocks = num_tiles / num_m_blocks;
+    const int group = tile / (GM * num_n_blocks);
+    const int first_m = group * GM;
+    const int gsz = min(num_m_blocks - first_m, GM);
+    const int within = tile - group * GM * num_n_blocks;
+    mb = first_m + within % gsz;
+    nb = within / gsz;
+  }
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2;   // 0..1 : rows wm*128 ..
+  const int wn = wave & 3;    // 0..3 : 64-column group
+  const int lc = lane & 15;
+  const int lr = lane >> 4;
+  const int ktiles = k / kUfBK;
+  const int kt32 = k >> 5;
+
+  // staging: wave w copies A pieces 4w..4w+3 and B pieces 4w..4w+3 of each stage
+  // (piece p = (tile index p>>1, ks = p&1); consecutive kt pieces are adjacent in global memory)
+  const uint4* a_src[4];
+  const uint4* b_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = wave * 4 + i;
+    int gmt = mb * 16 + (p >> 1);
+    const int max_mt = ((m + 15) >> 4) - 1;
+    gmt = gmt < max_mt ? gmt : max_mt;
+    a_src[i] = pa + ((int64_t)gmt * kt32 + (p & 1)) * 64 + lane;
+    int gnt = nb * 16 + (p >> 1);
+    const int max_nt = (n >> 4) - 1;
+    gnt = gnt < max_nt ? gnt : max_nt;
+    b_src[i] = pb + ((int64_t)gnt * kt32 + (p & 1)) * 64 + lane;
+  }
+  auto stage = [&](int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = wave * 4 + i;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[i] + (int64_t)kt * 128),
+                                       (lds_void_t*)(lds + buf * kStage + p * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[i] + (int64_t)kt * 128),
+                                       (lds_void_t*)(lds + buf * kStage + kBOff + p * 64), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  stage(0, 0);
+  __syncthreads();   // (emits vmcnt(0): stage 0 has landed)
+
+  const int frag = frag_swz(lr, lc);  // this lane's slot inside a piece
+  int cur = 0;
+  for (int kt = 0; kt < ktiles; ++kt) {
+    if (kt + 1 < ktiles) stage(cur ^ 1, kt + 1);
+    const uint4* abuf = lds + cur * kStage + (wm * 8) * 2 * 64 + frag;
+    const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 2 * 64 + frag;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 bf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bf[t] = bbuf[(t * 2 + ks) * 64];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint4 af = abuf[(i * 2 + ks) * 64];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = Mfma<T>::run(af, bf[t], acc[i][t]);
+      }
+    }
+    __syncthreads();   // all reads of `cur` done, next stage landed (vmcnt(0) + barrier)
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds 4 consecutive columns per (i, j) --------------------------------
+  const int ncol = nb * kUfBN + wn * 64 + 4 * lc;
+  if (ncol >= n) return;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = mb * kUfBM + wm * 128 + i * 16 + 4 * lr + j;
+      if (row < m) {
+        const uint2 v = make_uint2(Mfma<T>::pack(acc[i][0][j], acc[i][1][j]),
+                                   Mfma<T>::pack(acc[i][2][j], acc[i][3][j]));
+        *reinterpret_cast<uint2*>(c + (int64_t)row * n + ncol) = v;
+      }
+    }
+  }
+}
+
+static inline int64_t unfused_scratch_bytes(int m, int n, int k) {
+  const int64_t m_pad = ((int64_t)m + 15) / 16 * 16;
+  return ((int64_t)n + m_pad) * k * 2;
+}
+
+template <typename T>
+static int run_unfused(const GemmArgs& g) {
+  T* packed_b = static_cast<T*>(g.dq_ws);
+  T* packed_a = packed_b + (int64_t)g.n * g.k;
+  const int64_t words = (int64_t)(g.k / 8) * g.n;
+  if (g.zmode == kZeroAwq) {
+    hipLaunchKernelGGL((w4_dequant_pack_kernel<T, kZeroAwq>), dim3((words + 255) / 256), dim3(256), 0,
+                       g.stream, packed_b, g.qw, static_cast<const T*>(g.scales), g.qz, g.n, g.k,
+                       g.group);
+  } else {
+    hipLaunchKernelGGL((w4_dequant_pack_kernel<T, kZeroGptq>), dim3((words + 255) / 256), dim3(256), 0,
+                       g.stream, packed_b, g.qw, static_cast<const T*>(g.scales), g.qz, g.n, g.k,
+                       g.group);
+  }
+  int rc = check_launch("w4_dequant_pack");
+  if (rc) return rc;
+  const int m_tiles = (g.m + 15) / 16;
+  hipLaunchKernelGGL(pack_a_kernel<T>, dim3((g.k + 255) / 256, m_tiles), dim3(256), 0, g.stream,
+                     packed_a, static_cast<const T*>(g.a), g.m, g.k, g.lda);
+  rc = check_launch("pack_a");
+  if (rc) return rc;
+  const int num_m_blocks = (g.m + kUfBM - 1) / kUfBM;
+  const int num_n_blocks = (g.n + kUfBN - 1) / kUfBN;
+  const int num_tiles = num_m_blocks * num_n_blocks;
+  const size_t smem = (size_t)2 * 4096 * sizeof(uint4);  // 128 KiB
+  auto kern = gemm_packed_kernel<T>;
+  static bool attr_set = false;  // one flag per instantiation (T)
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) {
+      set_error("gemm_packed: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+      return MI355X_EUNSUPPORTED;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(kUfThreads), smem, g.stream, static_cast<T*>(g.c),
+                     reinterpret_cast<const uint4*>(packed_a), reinterpret_cast<const uint4*>(packed_b),
+                     g.m, g.n, g.k, num_m_blocks, num_tiles);
+  return check_launch("gemm_packed");
+}
+
+// returns 1 when not applicable (caller uses the fused kernel)
+int w4a16_gemm_unfused_dispatch(const GemmArgs& g, int dtype) {
+  if (g.dq_ws == nullptr) return 1;
+  if (g.dq_ws_bytes < unfused_scratch_bytes(g.m, g.n, g.k)) return 1;
+  if (g.k % kUfBK != 0 || g.n % 64 != 0) return 1;
+  if (g.m < 1024) return 1;   // too few 256-row tiles to fill 256 CUs below that
+  if (dtype == MI355X_BF16) return run_unfused<bf16_t>(g);
+  if (dtype == MI355X_F16) return run_unfused<f16_t>(g);
+  return 1;
+}
+
+}  // namespace mi355x
