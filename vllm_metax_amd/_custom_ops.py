@@ -413,9 +413,13 @@ _DQ_SCRATCH: dict = {}
 def _dq_scratch(m: int, n: int, k: int, device) -> Optional[torch.Tensor]:
     """Scratch for the dequantised weights of a prefill-sized GEMM (one buffer per device,
     grown to the largest n*k seen; the kernels of one stream run in order, so sharing is safe)."""
-    if m < 1024:
+    m_pad = (m + 15) // 16 * 16
+    if m <= 64:
+        need = m_pad * k * 2                    # decode: packed activations only
+    elif m < 1024:
         return None
-    need = (n + (m + 15) // 16 * 16) * k * 2    # packed weights + packed activations
+    else:
+        need = (n + m_pad) * k * 2              # prefill: packed weights + packed activations
     buf = _DQ_SCRATCH.get(device)
     if buf is None or buf.numel() < need:
         buf = torch.empty(need, dtype=torch.uint8, device=device)

@@ -96,6 +96,40 @@ __device__ __forceinline__ void load_zeros4(const uint32_t* __restrict__ zrow, i
   unpack_zeros4<ZMODE>(zrow[n >> 3], n, z);
 }
 
+// slot of lane-column lc, k-group lr inside a 1 KiB MFMA operand image (see w4a16_unfused.hip)
+__device__ __forceinline__ int frag_swz(int lr, int lc) {
+  // g = {0, 12, 2, 14}[lr]  ==  ((lr & 1) * 12) | ((lr & 2))
+  return lr * 16 + (lc ^ (((lr & 1) * 12) | (lr & 2)));
+}
+
+// ---- pack activations into operand images ------------------------------------------------
+// A [M, K] row-major -> pieces PA[mt][kt][64 slots x 16 B] in the same swizzled operand image
+// (slot swz(lr, lc) = A[16 mt + lc][32 kt + 8 lr .. +7]); rows >= M are zero.  One workgroup
+// packs 16 rows x 256 k: coalesced 16-B reads (a row's 512 contiguous bytes by 32 lanes), the
+// shuffle happens in LDS, the 8 KiB image is written out linearly.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_a_kernel(T* __restrict__ packed, const T* __restrict__ a,
+                                                     int m, int k, int64_t lda) {
+  __shared__ uint4 img[8 * 64];
+  const int mt = blockIdx.y;
+  const int k0 = blockIdx.x * 256;                 // first k of this block (8 pieces of 32)
+  const int kt32 = k >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = threadIdx.x + i * 256;         // 0..511 : row = idx / 32, chunk = idx % 32
+    const int r = idx >> 5, ch = idx & 31;
+    const int row = mt * 16 + r;
+    const int kk = k0 + ch * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < m && kk < k) v = *reinterpret_cast<const uint4*>(a + (int64_t)row * lda + kk);
+    img[(ch >> 2) * 64 + frag_swz(ch & 3, r)] = v;
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(packed) + ((int64_t)mt * kt32 + (k0 >> 5)) * 64;
+  const int pieces = min(8, kt32 - (k0 >> 5));
+  for (int idx = threadIdx.x; idx < pieces * 64; idx += 256) dst[idx] = img[idx];
+}
+
 struct GemmArgs {
   void* c;
   const void* a;

@@ -162,12 +162,12 @@ constexpr int kSmBN = 64;
 constexpr int kSmWaves = 8;
 constexpr int kSmThreads = kSmWaves * 64;
 
-template <typename T, int MT, int ZMODE, bool GPOW2>
+template <typename T, int MT, int ZMODE, bool GPOW2, bool APACK>
 __global__ __launch_bounds__(kSmThreads, 4) void w4a16_gemm_small_m_kernel(
     T* __restrict__ c, float* __restrict__ acc_ws, const T* __restrict__ a,
     const uint32_t* __restrict__ qw, const T* __restrict__ scales,
     const uint32_t* __restrict__ qz, int m, int n, int k, int group, int group_shift,
-    int64_t lda, int ksteps_per_split) {
+    int64_t lda, int ksteps_per_split, const uint4* __restrict__ a_packed) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* red = reinterpret_cast<float*>(smem);  // [4][MT*16][64] fp32
 
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(kSmThreads, 4) void w4a16_gemm_small_m_kernel(
     arow[i] = a + (int64_t)r * lda + 8 * (lane & 3);
   }
   const int perm_addr = (4 * lc + lr) * 4;  // ds_bpermute byte address of the source lane
+  const int pk_slot = frag_swz(lr, lc);     // slot of this lane inside a packed operand image
   const int n8 = n >> 3;
 
   uint4 bq[2];
@@ -217,13 +218,19 @@ __global__ __launch_bounds__(kSmThreads, 4) void w4a16_gemm_small_m_kernel(
   };
   auto compute = [&](int slot, int s) {
     uint4 af[MT];
+    if constexpr (APACK) {
+      // activations pre-tiled into MFMA operand images: one lane-linear 1 KiB load per tile
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const uint4 raw = *reinterpret_cast<const uint4*>(arow[i] + s * 32);
-      af[i].x = __builtin_amdgcn_ds_bpermute(perm_addr, raw.x);
-      af[i].y = __builtin_amdgcn_ds_bpermute(perm_addr, raw.y);
-      af[i].z = __builtin_amdgcn_ds_bpermute(perm_addr, raw.z);
-      af[i].w = __builtin_amdgcn_ds_bpermute(perm_addr, raw.w);
+      for (int i = 0; i < MT; ++i) af[i] = a_packed[((int64_t)i * (k >> 5) + s) * 64 + pk_slot];
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(arow[i] + s * 32);
+        af[i].x = __builtin_amdgcn_ds_bpermute(perm_addr, raw.x);
+        af[i].y = __builtin_amdgcn_ds_bpermute(perm_addr, raw.y);
+        af[i].z = __builtin_amdgcn_ds_bpermute(perm_addr, raw.z);
+        af[i].w = __builtin_amdgcn_ds_bpermute(perm_addr, raw.w);
+      }
     }
     T sct[4];
     *reinterpret_cast<uint2*>(sct) = scq[slot];
@@ -364,12 +371,27 @@ static int launch_small_m(const GemmArgs& g, int row0, int rows) {
     group_shift = 0;
     while ((1 << group_shift) < g.group) ++group_shift;
   }
+  // optional: re-tile the activations into MFMA operand images first (one tiny launch)
+  const uint4* a_packed = nullptr;
+  const int64_t pack_bytes = (int64_t)mt * 16 * g.k * 2;
+  if (g.dq_ws != nullptr && g.dq_ws_bytes >= pack_bytes && g.k % 32 == 0) {
+    hipLaunchKernelGGL(pack_a_kernel<T>, dim3((g.k + 255) / 256, mt), dim3(256), 0, g.stream,
+                       static_cast<T*>(g.dq_ws), a, rows, g.k, g.lda);
+    int prc = check_launch("pack_a(small)");
+    if (prc) return prc;
+    a_packed = static_cast<const uint4*>(g.dq_ws);
+  }
   dim3 grid(col_tiles, sk), block(kSmThreads);
-#define LAUNCH_SM2(MTV, P2)                                                                  \
-  hipLaunchKernelGGL((w4a16_gemm_small_m_kernel<T, MTV, ZMODE, P2>), grid, block,            \
-                     (size_t)(kSmWaves / 2) * MTV * 16 * 64 * sizeof(float), g.stream, c, ws, a, g.qw,     \
-                     static_cast<const T*>(g.scales), g.qz, rows, g.n, g.k, g.group,         \
-                     group_shift, g.lda, steps_per_split)
+#define LAUNCH_SM3(MTV, P2, AP)                                                               \
+  hipLaunchKernelGGL((w4a16_gemm_small_m_kernel<T, MTV, ZMODE, P2, AP>), grid, block,         \
+                     (size_t)(kSmWaves / 2) * MTV * 16 * 64 * sizeof(float), g.stream, c, ws, a, \
+                     g.qw, static_cast<const T*>(g.scales), g.qz, rows, g.n, g.k, g.group,     \
+                     group_shift, g.lda, steps_per_split, a_packed)
+#define LAUNCH_SM2(MTV, P2)                    \
+  do {                                         \
+    if (a_packed) LAUNCH_SM3(MTV, P2, true);   \
+    else LAUNCH_SM3(MTV, P2, false);           \
+  } while (0)
 #define LAUNCH_SM(MTV)                      \
   do {                                      \
     if (group_shift >= 0) LAUNCH_SM2(MTV, true); \
@@ -378,6 +400,7 @@ static int launch_small_m(const GemmArgs& g, int row0, int rows) {
   if (mt <= 1) LAUNCH_SM(1);
   else if (mt <= 2) LAUNCH_SM(2);
   else LAUNCH_SM(4);
+#undef LAUNCH_SM3
 #undef LAUNCH_SM2
 #undef LAUNCH_SM
   int rc = check_launch("w4a16_gemm_small_m");

@@ -25,11 +25,6 @@
 
 namespace mi355x {
 
-__device__ __forceinline__ int frag_swz(int lr, int lc) {
-  // g = {0, 12, 2, 14}[lr]  ==  ((lr & 1) * 12) | ((lr & 2))
-  return lr * 16 + (lc ^ (((lr & 1) * 12) | (lr & 2)));
-}
-
 // ---------------------------------------------------------------- kernel 1: dequant + pack
 // one thread per shuffled word (kk, n): 8 consecutive k of column n -> one 16-byte slot.
 template <typename T, int ZMODE>
@@ -60,33 +55,7 @@ __global__ void w4_dequant_pack_kernel(T* __restrict__ packed, const uint32_t* _
   *dst = v;
 }
 
-// ---------------------------------------------------------------- kernel 2: pack activations
-// A [M, K] row-major -> pieces PA[mt][kt][64 slots x 16 B] in the same swizzled operand image
-// (slot swz(lr, lc) = A[16 mt + lc][32 kt + 8 lr .. +7]); rows >= M are zero.  One workgroup
-// packs 16 rows x 256 k: coalesced 16-B reads (a row's 512 contiguous bytes by 32 lanes), the
-// shuffle happens in LDS, the 8 KiB image is written out linearly.
-template <typename T>
-__global__ __launch_bounds__(256) void pack_a_kernel(T* __restrict__ packed, const T* __restrict__ a,
-                                                     int m, int k, int64_t lda) {
-  __shared__ uint4 img[8 * 64];
-  const int mt = blockIdx.y;
-  const int k0 = blockIdx.x * 256;                 // first k of this block (8 pieces of 32)
-  const int kt32 = k >> 5;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = threadIdx.x + i * 256;         // 0..511 : row = idx / 32, chunk = idx % 32
-    const int r = idx >> 5, ch = idx & 31;
-    const int row = mt * 16 + r;
-    const int kk = k0 + ch * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < m && kk < k) v = *reinterpret_cast<const uint4*>(a + (int64_t)row * lda + kk);
-    img[(ch >> 2) * 64 + frag_swz(ch & 3, r)] = v;
-  }
-  __syncthreads();
-  uint4* dst = reinterpret_cast<uint4*>(packed) + ((int64_t)mt * kt32 + (k0 >> 5)) * 64;
-  const int pieces = min(8, kt32 - (k0 >> 5));
-  for (int idx = threadIdx.x; idx < pieces * 64; idx += 256) dst[idx] = img[idx];
-}
+// (kernel 2, pack_a_kernel: activations -> operand images, lives in w4a16.cuh)
 
 // ---------------------------------------------------------------- kernel 3: the GEMM
 // C[M,N] = PA . PB^T with BOTH operands pre-packed as MFMA operand images: every staging
