@@ -224,13 +224,18 @@ int mi355x_awq_dequantize(void* out, const uint32_t* qweight, const void* scales
 
 /* awq_gemm: C[M,N] = A[M,K] . ((Q - Z) * S); Q in the exllama layout produced by
  * awq_to_gptq_4bit, qzeros [K/g, N/8] in AWQ nibble order, scales [K/g, N].
- * `workspace` (float, >= m*n, may be NULL: then K is never split across workgroups) is the
- * reference's temp_space and, like it (awq.py:140-147: a fresh torch.zeros), MUST be all zero
- * on entry; the call hands it back all zero, so one buffer can be reused without a memset.
- * `dq_workspace` (>= (n + roundup(m,16))*k*2 bytes, may be NULL) is scratch for prefill-sized
- * M (>= 1024): weights are dequantised once and activations re-tiled into MFMA operand images
- * in it, then a pure-MFMA GEMM follows (same numerics); without it the fused dequant-GEMM
- * kernel is used for every M.  Contents on exit are unspecified.
+ * `workspace` (float, may be NULL: then K is never split across workgroups) is the
+ * reference's temp_space (awq.py:140-147).  For M <= 64 the kernel may split K over up to
+ * workspace_elems / (min(m,64)*n) workgroups, each writing one fp32 partial slab [m, n] into it;
+ * a second kernel adds the slabs in a fixed order and rounds once (no atomics: results do not
+ * depend on timing).  8*m*n elements allow every split the planner wants.  It need not be
+ * zeroed; contents on exit are unspecified.
+ * `dq_workspace` (16-byte aligned, may be NULL) is scratch for re-tiled operands:
+ *   - M <= 64: >= roundup(m,16)*k*2 bytes: the activations are re-tiled into MFMA operand
+ *     images, which selects the LDS-DMA "stripe" decode kernel (k % 128 == 0, group 32/64/128k);
+ *   - M >= 1024: >= (n + roundup(m,16))*k*2 bytes: weights are dequantised once and
+ *     activations re-tiled, then a pure-MFMA GEMM follows (same numerics).
+ *   Without it the register-staged kernels are used.  Contents on exit are unspecified.
  * ref: csrc/quantization/awq/gemm_kernels.cu:410-463, :283-318, :186-281. */
 int mi355x_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* scales,
                     const uint32_t* qzeros, float* workspace, int64_t workspace_elems,

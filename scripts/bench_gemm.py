@@ -1,13 +1,16 @@
 """Micro-benchmark of the w4a16 GEMM at the Llama-3-8B layer shapes (run on the GPU box).
 usage: python scripts/bench_gemm.py [M ...]   (default 64 and 8192)"""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from vllm_metax_amd import _custom_ops as ops
 d = torch.device("cuda:0")
 RESIDENT = "--resident" in sys.argv
 Ms = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [64, 8192]
 shapes = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096)]
 g = 128
+ONLY = [a.split("=")[1] for a in sys.argv if a.startswith("--only=")]
+if ONLY:
+    shapes = [s for s in shapes if s[0] in ONLY]
 for M in Ms:
     tot = 0.0
     for name, K, N in shapes:
@@ -15,7 +18,7 @@ for M in Ms:
         qz = torch.randint(-2**31, 2**31 - 1, (K // g, N // 8), dtype=torch.int32, device=d)
         sc = (torch.rand(K // g, N, device=d) * 4e-3 + 1e-3).to(torch.bfloat16)
         x = (torch.randn(M, K, device=d) * 0.5).to(torch.bfloat16)
-        ws = torch.zeros(M, N, dtype=torch.float32, device=d) if M <= 64 else torch.empty(0)
+        ws = torch.zeros(8 * M * N, dtype=torch.float32, device=d) if M <= 64 else torch.empty(0)
         # rotate over 8 weight copies so that the weights are not L2/MALL resident
         copies = [qw.clone() for _ in range(8 if (M <= 64 and not RESIDENT) else 1)]
         for c in copies[:2]:

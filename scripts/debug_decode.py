@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from vllm_metax_amd import harness, _custom_ops as ops
 torch.manual_seed(0)
 cfg = harness.ModelConfig.tiny("awq")

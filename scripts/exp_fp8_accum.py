@@ -1,6 +1,6 @@
 """Diagnostic: how exact is v_mfma_f32_16x16x32_fp8_fp8 accumulation?  (run on the GPU box)"""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from vllm_metax_amd import _custom_ops as ops
 from oracle import ref_ops as R
 FP8 = torch.float8_e4m3fn

@@ -1,6 +1,6 @@
 """Single-shape driver for rocprofv3 PMC runs of the large-M w4a16 GEMM (qkv shape, M=8192)."""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from vllm_metax_amd import _custom_ops as ops
 d = torch.device("cuda:0")
 M, K, N, g = 8192, 4096, 6144, 128

@@ -1,6 +1,6 @@
 """Single-shape driver for rocprofv3 PMC runs of the small-M w4a16 GEMM (gate_up, M=64)."""
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from vllm_metax_amd import _custom_ops as ops
 d = torch.device("cuda:0")
 M, K, N, g = 64, 4096, 28672, 128

@@ -96,7 +96,7 @@ def test_awq_gemm_small_shapes(dtype, m, k, n, group):
     ref = R.awq_gemm(x, q2, sc, qz)
     d = dev()
     q2d = ops().awq_to_gptq_4bit(qw.to(d))
-    ws = torch.zeros(m, n, dtype=torch.float32, device=d)
+    ws = torch.full((8 * min(m, 64) * n,), float("nan"), dtype=torch.float32, device=d)  # scratch: any contents
     out = ops().awq_gemm(x.to(d), q2d, qz.to(d), sc.to(d), 8, ws, dtype == torch.bfloat16)
     _check_gemm(out, ref, f"awq_gemm m={m}")
     # without a workspace the kernel must not split K and give the same answer
@@ -113,7 +113,7 @@ def test_awq_gemm_llama3_8b_decode_shapes(k, n):
     ref = R.awq_gemm(x, R.awq_to_gptq_4bit(qw), sc, qz)
     d = dev()
     q2d = ops().awq_to_gptq_4bit(qw.to(d))
-    ws = torch.zeros(m, n, dtype=torch.float32, device=d)
+    ws = torch.full((8 * min(m, 64) * n,), float("nan"), dtype=torch.float32, device=d)  # scratch: any contents
     out = ops().awq_gemm(x.to(d), q2d, qz.to(d), sc.to(d), 8, ws, True)
     _check_gemm(out, ref, "awq_gemm llama3")
 
@@ -150,7 +150,7 @@ def test_gptq_gemm(dtype, m, sym, act_order):
     qd = qw.to(d).clone()
     pd = perm.to(d) if act_order else perm
     ops().gptq_shuffle(qd, pd, 4)
-    ws = torch.zeros(m, n, dtype=torch.float32, device=d)
+    ws = torch.full((8 * min(m, 64) * n,), float("nan"), dtype=torch.float32, device=d)  # scratch: any contents
     pspace = torch.empty(m, k, dtype=torch.float16, device=d) if act_order else torch.empty(0)
     out = ops().gptq_gemm(x.to(d), qd, qz.to(d), sc.to(d), pd, True, 4, group, pspace, ws,
                           dtype == torch.bfloat16)
@@ -168,7 +168,7 @@ def test_gptq_gemm_qwen2_72b_tp8_shapes():
         d = dev()
         qd = qw.to(d).clone()
         ops().gptq_shuffle(qd, torch.empty(0, dtype=torch.int32), 4)
-        ws = torch.zeros(m, n, dtype=torch.float32, device=d)
+        ws = torch.full((8 * min(m, 64) * n,), float("nan"), dtype=torch.float32, device=d)  # scratch: any contents
         out = ops().gptq_gemm(x.to(d), qd, qz.to(d), sc.to(d), torch.empty(0, dtype=torch.int32),
                               True, 4, group, torch.empty(0), ws, True)
         _check_gemm(out, ref, f"gptq_gemm {k}x{n}")

@@ -7,6 +7,7 @@ the HIP library has not been built — there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 from pathlib import Path
 
@@ -69,11 +70,14 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    path = LIB_PATH
+    if os.environ.get("MI355X_HOTPATH_LIB"):      # kernel experiments: an alternative build
+        path = type(LIB_PATH)(os.environ["MI355X_HOTPATH_LIB"])
+    if not path.exists():
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m vllm_metax_amd.build` "
+            f"{path} is missing: build it with `python -m vllm_metax_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
-    lib = ctypes.CDLL(str(LIB_PATH))
+    lib = ctypes.CDLL(str(path))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

@@ -40,7 +40,7 @@ HIP_FLAGS = [
     "-Wno-unused-function",
     "-Wno-unused-variable",
     f"-I{INCLUDE}",
-]
+] + os.environ.get("MI355X_EXTRA_HIPFLAGS", "").split()   # (kernel ablation experiments)
 
 
 def _newer(target: Path, deps: list[Path]) -> bool:

@@ -35,6 +35,29 @@ int check_launch(const char* what);
     }                                    \
   } while (0)
 
+// ---- asynchronous global -> LDS copies (LDS-DMA) -----------------------------------------
+// One wave copies 64 x 16 B: lane l reads 16 B at `gptr` (per lane) and the hardware writes
+// them at LDS byte address lds_base + 16 * l (lds_base is wave-uniform, in M0).
+// Spelled as inline asm on purpose: with the builtin the compiler's wait-count pass cannot
+// tell which LDS bytes a pending DMA will write and puts `s_waitcnt vmcnt(0)` in front of the
+// next ds_read of ANY LDS address, which serialises every multi-stage pipeline.  These copies
+// are invisible to that pass, so the kernel must order them itself: lds_dma_wait<N>() (at most
+// N of this wave's copies still in flight; they complete in issue order) and then a barrier
+// before another wave reads the bytes.
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+               :
+               : "v"(gptr), "s"(lds_base)
+               : "memory");  // (M0 is reserved: the compiler never keeps a value in it)
+}
+template <int N>
+__device__ __forceinline__ void lds_dma_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+
 // ---- scalar conversions ------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ float to_f32(T v) {

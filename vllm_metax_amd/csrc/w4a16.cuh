@@ -35,7 +35,11 @@ struct Mfma<f16_t> {
 
 // byte -> float conversions: hipcc only pattern-matches v_cvt_f32_ubyte0 and builds the other
 // three out of shift / bfe / and (3 VALU ops instead of 1), so they are spelled out.
-__device__ __forceinline__ float cvt_ubyte0(uint32_t x) { return (float)(x & 0xFFu); }
+__device__ __forceinline__ float cvt_ubyte0(uint32_t x) {
+  float r;  // (as asm too: written as (float)(x & 0xff) the mask is re-derived from the source word)
+  asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 __device__ __forceinline__ float cvt_ubyte1(uint32_t x) {
   float r;
   asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(r) : "v"(x));
@@ -58,19 +62,22 @@ template <typename T>
 __device__ __forceinline__ uint4 dequant_word(uint32_t w, float s, float zs) {
   const uint32_t t0 = w & 0x0F0F0F0Fu;         // bytes: k0, k4, k1, k5
   const uint32_t t1 = (w >> 4) & 0x0F0F0F0Fu;  // bytes: k2, k6, k3, k7
-  const float k0 = cvt_ubyte0(t0);
-  const float k4 = cvt_ubyte1(t0);
-  const float k1 = cvt_ubyte2(t0);
-  const float k5 = cvt_ubyte3(t0);
-  const float k2 = cvt_ubyte0(t1);
-  const float k6 = cvt_ubyte1(t1);
-  const float k3 = cvt_ubyte2(t1);
-  const float k7 = cvt_ubyte3(t1);
+  // element pairs go through v_pk_fma_f32 (two IEEE fmas per instruction, s / zs broadcast)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t s2 = {s, s}, z2 = {zs, zs};
+  f32x2_t k01 = {cvt_ubyte0(t0), cvt_ubyte2(t0)};
+  f32x2_t k23 = {cvt_ubyte0(t1), cvt_ubyte2(t1)};
+  f32x2_t k45 = {cvt_ubyte1(t0), cvt_ubyte3(t0)};
+  f32x2_t k67 = {cvt_ubyte1(t1), cvt_ubyte3(t1)};
+  k01 = __builtin_elementwise_fma(k01, s2, z2);
+  k23 = __builtin_elementwise_fma(k23, s2, z2);
+  k45 = __builtin_elementwise_fma(k45, s2, z2);
+  k67 = __builtin_elementwise_fma(k67, s2, z2);
   uint4 r;
-  r.x = Mfma<T>::pack(fmaf(k0, s, zs), fmaf(k1, s, zs));
-  r.y = Mfma<T>::pack(fmaf(k2, s, zs), fmaf(k3, s, zs));
-  r.z = Mfma<T>::pack(fmaf(k4, s, zs), fmaf(k5, s, zs));
-  r.w = Mfma<T>::pack(fmaf(k6, s, zs), fmaf(k7, s, zs));
+  r.x = Mfma<T>::pack(k01.x, k01.y);
+  r.y = Mfma<T>::pack(k23.x, k23.y);
+  r.z = Mfma<T>::pack(k45.x, k45.y);
+  r.w = Mfma<T>::pack(k67.x, k67.y);
   return r;
 }
 
@@ -128,6 +135,25 @@ __global__ __launch_bounds__(256) void pack_a_kernel(T* __restrict__ packed, con
   uint4* dst = reinterpret_cast<uint4*>(packed) + ((int64_t)mt * kt32 + (k0 >> 5)) * 64;
   const int pieces = min(8, kt32 - (k0 >> 5));
   for (int idx = threadIdx.x; idx < pieces * 64; idx += 256) dst[idx] = img[idx];
+}
+
+// out = T(slab[0] + slab[1] + ... + slab[sk-1])  (fixed order: results do not depend on timing)
+template <typename T>
+__global__ void w4a16_sum_slabs_kernel(T* __restrict__ out, const float* __restrict__ slabs,
+                                       int64_t n4, int sk) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4* p = reinterpret_cast<const float4*>(slabs) + i;
+  float4 v = p[0];
+  for (int s = 1; s < sk; ++s) {
+    const float4 u = p[(int64_t)s * n4];
+    v.x += u.x;
+    v.y += u.y;
+    v.z += u.z;
+    v.w += u.w;
+  }
+  T o[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
+  reinterpret_cast<uint2*>(out)[i] = *reinterpret_cast<const uint2*>(o);
 }
 
 struct GemmArgs {

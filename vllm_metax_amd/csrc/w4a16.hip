@@ -153,7 +153,7 @@ __global__ void permute_cols_kernel(T* __restrict__ out, const T* __restrict__ i
 // ------------------------------------------------------------------ small-M kernel
 // C[M<=64, N] tile 64 x 64 per workgroup of 8 waves; the waves split the K range of the
 // workgroup (k-step = 32, interleaved) and are summed through LDS (tree); blockIdx.y splits
-// K across workgroups (fp32 atomics into `acc_ws` when gridDim.y > 1).
+// K across workgroups (fp32 partial slabs acc_ws[split][m][n] when gridDim.y > 1).
 // Regime: weights are read exactly once (HBM-bound), the kernel is otherwise limited by the
 // dequant VALU work and by memory latency, so it runs 8 waves x 2 workgroups per CU
 // (<= 128 VGPRs) and lets wave-level parallelism hide the latency; weights are prefetched
@@ -320,34 +320,17 @@ __global__ __launch_bounds__(kSmThreads, 4) void w4a16_gemm_small_m_kernel(
                                    Mfma<T>::pack(acc[i][2][j], acc[i][3][j]));
         *reinterpret_cast<uint2*>(c + (int64_t)row * n + ncol) = v;
       } else {
-        float* dst = acc_ws + (int64_t)row * n + ncol;
-        atomicAdd(dst + 0, acc[i][0][j]);
-        atomicAdd(dst + 1, acc[i][1][j]);
-        atomicAdd(dst + 2, acc[i][2][j]);
-        atomicAdd(dst + 3, acc[i][3][j]);
+        float* dst = acc_ws + ((int64_t)blockIdx.y * m + row) * n + ncol;
+        *reinterpret_cast<float4*>(dst) =
+            make_float4(acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]);
       }
     }
   }
 }
 
-// split-K epilogue: out = T(ws); ws is handed back ZEROED, which is the state the caller must
-// provide it in (the reference's temp_space is a fresh torch.zeros, awq.py:140-147).
-template <typename T>
-__global__ void f32_to_t_kernel(T* __restrict__ out, float* __restrict__ in, int64_t n4) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4) return;
-  const float4 v = reinterpret_cast<const float4*>(in)[i];
-  reinterpret_cast<float4*>(in)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  T o[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
-  if constexpr (sizeof(T) == 2) {
-    reinterpret_cast<uint2*>(out)[i] = *reinterpret_cast<const uint2*>(o);
-  } else {
-    reinterpret_cast<float4*>(out)[i] = v;
-  }
-}
-
 int w4a16_gemm_large_m_dispatch(const GemmArgs& g, int dtype);  // w4a16_large.hip
 int w4a16_gemm_unfused_dispatch(const GemmArgs& g, int dtype);  // w4a16_unfused.hip
+int w4a16_gemm_stripe_dispatch(const GemmArgs& g, int dtype, int row0, int rows);  // w4a16_stripe.hip
 
 template <typename T, int ZMODE>
 static int launch_small_m(const GemmArgs& g, int row0, int rows) {
@@ -356,11 +339,12 @@ static int launch_small_m(const GemmArgs& g, int row0, int rows) {
   const int col_tiles = g.n / kSmBN;
   const int total_steps = g.k / 32;
   // Split K across workgroups only when the column tiles alone cannot fill the chip: every
-  // extra split adds rows*n fp32 atomics (~1.3 TB/s chip-wide).  Keep >= 16 k-steps per split.
+  // split writes a rows*n fp32 partial slab that the sum kernel reads back.  >= 16 k-steps per split.
   int sk = 1;
-  const bool can_split = g.ws != nullptr && g.ws_elems >= (int64_t)rows * g.n;
-  if (can_split) {
-    while (col_tiles * sk < 256 && total_steps / (sk * 2) >= 16) sk *= 2;
+  if (g.ws != nullptr) {
+    while (col_tiles * sk < 256 && total_steps / (sk * 2) >= 16 &&
+           g.ws_elems >= (int64_t)(sk * 2) * rows * g.n)
+      sk *= 2;
   }
   const int steps_per_split = (total_steps + sk - 1) / sk;
   sk = (total_steps + steps_per_split - 1) / steps_per_split;
@@ -407,9 +391,9 @@ static int launch_small_m(const GemmArgs& g, int row0, int rows) {
   if (rc) return rc;
   if (sk > 1) {
     const int64_t n4 = (int64_t)rows * g.n / 4;
-    hipLaunchKernelGGL(f32_to_t_kernel<T>, dim3((n4 + 255) / 256), dim3(256), 0, g.stream, c, ws,
-                       n4);
-    rc = check_launch("w4a16_gemm_convert");
+    hipLaunchKernelGGL(w4a16_sum_slabs_kernel<T>, dim3((n4 + 255) / 256), dim3(256), 0, g.stream, c,
+                       ws, n4, sk);
+    rc = check_launch("w4a16_sum_slabs");
   }
   return rc;
 }
@@ -426,7 +410,12 @@ static int run_gemm_t(const GemmArgs& g, int dtype) {
   }
   for (int row0 = 0; row0 < g.m; row0 += 64) {
     const int rows = (g.m - row0) < 64 ? (g.m - row0) : 64;
-    int rc = g.zmode == kZeroAwq ? launch_small_m<T, kZeroAwq>(g, row0, rows)
+    int rc = w4a16_gemm_stripe_dispatch(g, dtype, row0, rows);
+    if (rc != 1) {
+      if (rc) return rc;
+      continue;
+    }
+    rc = g.zmode == kZeroAwq ? launch_small_m<T, kZeroAwq>(g, row0, rows)
                                  : launch_small_m<T, kZeroGptq>(g, row0, rows);
     if (rc) return rc;
   }

@@ -1,0 +1,482 @@
+// w4a16_stripe.hip — the decode-shaped (M <= 64) w4a16 GEMM: C[M, N] = A[M, K] . dequant(W)[K, N]
+//
+// Replaces, for the shapes it accepts, the generic small-M kernel of w4a16.hip on the op surface
+// of the reference's awq_gemm / gptq_gemm (csrc/quantization/awq/gemm_kernels.cu:1165-1221,
+// csrc/quantization/gptq/q_gemm.cu:2354-2413) — same operands, same exact dequantisation
+// T(fma(q, s, -z*s)), fp32 accumulation.
+//
+// Regime (M = 64, Llama-3-8B layer shapes): every weight byte is read once from HBM, the
+// activations (M x K, <= 1.8 MB) are re-read by every workgroup from its XCD's L2.  What bounds a
+// CU is (a) its L2/HBM -> LDS fill rate (~70 GB/s per CU) and (b) the dequant VALU work
+// (~20 VALU per packed word).  So:
+//   * one workgroup owns a STRIPE of BN = 64*NW columns (NW = 2 or 4 "column waves") and a
+//     contiguous K range; its 8 waves are NW column waves x KW = 8/NW K waves.  The column waves
+//     share the activation bytes of a k-step through LDS, so A traffic per weight byte is 4/NW of
+//     what a 64-column tile pays.
+//   * weights, activations (pre-tiled MFMA operand images, pack_a_kernel), scales and zero
+//     points all arrive by LDS-DMA into a ring of kStStages stages of 128 k; the copies of
+//     stage t+3 are issued before the math of stage t, nothing is staged through VGPRs and
+//     ~100 KiB per CU stay in flight.
+//   * K is split across workgroups only as far as needed to put ~all CUs on the weight
+//     stream; partial tiles go to fp32 slabs ws[split][M][N] with plain stores and one small
+//     kernel adds the slabs in split order and rounds to T (deterministic, no atomics: float
+//     atomics run at ~1.3 TB/s chip-wide, plain stores at ~6).
+#include <cstdio>
+#include <cstdlib>
+
+#include "w4a16.cuh"
+
+namespace mi355x {
+
+constexpr int kStThreads = 512;
+constexpr int kStBK = 128;
+
+template <int MT, int NW, int SETS>
+struct StripeCfg {
+  static constexpr int BN = 64 * NW;
+  static constexpr int KW = 8 / NW;              // waves along K
+  static constexpr int KS_PER_WAVE = 4 / KW;     // k-steps (of 32) of one stage per wave
+  static constexpr int W_ROW_BYTES = BN * 4;     // one packed row = 8 k of every column
+  static constexpr int W_BYTES = 16 * W_ROW_BYTES;
+  static constexpr int SC_LANES = 8 * NW;        // 16-B pieces of the BN scales (2 B each)
+  static constexpr int Z_LANES = 2 * NW;         // 16-B pieces of the BN/8 zero words
+  static constexpr int SET_BYTES = 16 * (SC_LANES + Z_LANES);
+  static constexpr int A_IMG_BYTES = MT * 4096;  // MT x 4 operand images of 1 KiB
+  static constexpr int A_BYTES = A_IMG_BYTES + SETS * SET_BYTES;  // A-ring slot: images + sets
+  // ring depths: the weight stream comes from HBM (~2-3 us under load) and needs >= 48 KiB in
+  // flight per CU; activations / scales come from L2 and need two stages ahead.
+#ifdef STRIPE_DEEP
+  static constexpr int W_DEPTH = NW == 2 ? 8 : 5;
+  static constexpr int A_DEPTH = 3;
+  static constexpr int WAVES_PER_SIMD = 2;
+#else
+#ifndef STRIPE_AD
+#define STRIPE_AD 3
+#endif
+  static constexpr int W_DEPTH = 3;
+  static constexpr int A_DEPTH = STRIPE_AD;
+  static constexpr int WAVES_PER_SIMD = 2;
+#endif
+  static constexpr int W_COPIES = NW;            // per weight-loader wave (waves 0-3) and stage
+  static constexpr int A_COPIES = MT + 1;        // per activation-loader wave (4-7): images + one set
+  static constexpr int A_RING = 0;
+  static constexpr int W_RING = A_DEPTH * A_BYTES;
+  static constexpr int RING_BYTES = W_RING + W_DEPTH * W_BYTES;
+  static constexpr int RED_BYTES = (KW - 1) * NW * MT * 16 * 64 * 4;
+  static constexpr int LDS_BYTES = RING_BYTES > RED_BYTES ? RING_BYTES : RED_BYTES;
+};
+
+// streamed-once variant of lds_dma16 (nt: do not keep the line in L2 for somebody else)
+__device__ __forceinline__ void lds_dma16_nt(const void* gptr, uint32_t lds_base) {
+#ifdef STRIPE_NO_NT
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+#else
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
+#endif
+               :
+               : "v"(gptr), "s"(lds_base)
+               : "memory");
+}
+
+template <typename T, int MT, int NW, int ZMODE, int SETS>
+__global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIMD)) void w4a16_gemm_stripe_kernel(
+    T* __restrict__ c, float* __restrict__ slabs, const T* __restrict__ a, int64_t lda,
+    const uint32_t* __restrict__ qw, const T* __restrict__ scales, const uint32_t* __restrict__ qz,
+    int m, int n, int k, int group, int stages_per_split) {
+  using Cfg = StripeCfg<MT, NW, SETS>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wn = wave % NW;   // column wave: columns n0 + 64*wn ..
+  const int wk = wave / NW;   // K wave: k-steps wk*KS_PER_WAVE .. of every stage
+  const int lc = lane & 15;
+  const int lr = lane >> 4;
+  const int n0 = blockIdx.x * Cfg::BN;
+  const int kt32 = k >> 5;
+  const int total_stages = k / kStBK;
+  const int s_begin = blockIdx.y * stages_per_split;
+  const int s_end = min(s_begin + stages_per_split, total_stages);
+  const int nst = s_end - s_begin;
+  // Every workgroup sweeps its K range from a different starting stage (wrapping around).  All
+  // workgroups read the SAME activation rows, a stage's 256-byte row segments are one row pitch
+  // apart and so live in ONE L2 channel (256-B interleave, pitch a multiple of 4 KiB): in
+  // lock-step the 28-32 workgroups of an XCD would all queue on that channel.  Workgroups b, b+8,
+  // b+16.. share an XCD (round-robin dispatch), so consecutive b/8 get consecutive start stages.
+  const int rot = nst > 0 ? (int)(((blockIdx.x >> 3) + 4u * (blockIdx.x & 7) + 7u * blockIdx.y) % (unsigned)nst) : 0;
+  auto stage_of = [&](int i) {
+    int s = i + rot;
+    s = s >= nst ? s - nst : s;
+    return s_begin + s;
+  };
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+
+  // ---- loader roles: the LDS-DMA queue of a wave completes in issue order, so the deep weight
+  // ring and the shallow activation ring are fed by different waves (each waits on its own).
+  const bool w_loader = wave < 4;
+  const int lw = wave & 3;
+  // weights: piece p = 1 KiB = 4/NW packed rows of the stripe; loader lw copies pieces lw*NW ..
+  const uint32_t* w_src[Cfg::W_COPIES];
+  {
+    constexpr int RPP = 4 / NW;          // rows per piece
+    constexpr int LPR = 64 / RPP;        // lanes per row
+#pragma unroll
+    for (int j = 0; j < Cfg::W_COPIES; ++j) {
+      const int p = lw * Cfg::W_COPIES + j;
+      const int r = p * RPP + lane / LPR;
+      int col = n0 + 4 * (lane % LPR);
+      col = col <= n - 4 ? col : n - 4;
+      w_src[j] = qw + (int64_t)r * n + col;
+#ifdef STRIPE_TEST_LINEAR
+      w_src[j] = qw + (int64_t)blockIdx.x * (k / 8) * Cfg::BN + (int64_t)p * 256 + lane * 4;
+#endif
+    }
+  }
+  // activations: loader lw copies the 4 k-step images of row tile i for i = 0..MT-1, k-step lw
+  // Activations, no pre-tiling pass: a copy moves 4 rows x 256 contiguous bytes (the 128 k of the
+  // stage) of row tile i, rows 4j .. 4j+3 (j = lw), into piece (i, j) of the stage.  The LDS side
+  // of an LDS-DMA is lane-linear, so WHICH 16 bytes lane l fetches decides the layout:
+  //   slot 16 r + 4 (ks ^ j) + (lr ^ r)   <-  A[16 i + 4 j + r][32 ks + 8 lr .. +7]
+  // A lane quad still reads one 64-byte run and 16 lanes one 256-byte row segment (coalesced
+  // like a plain copy); the two XORs make the 16 lanes of every ds_read_b128 lane group
+  // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ..) hit 16 different bank quads when lane (lr, lc)
+  // reads row lc, k-group lr of one k-step — the MFMA A operand, conflict-free.
+  const T* a_src[MT];
+  {
+    const int r = lane >> 4, ks = ((lane >> 2) & 3) ^ lw, a_lr = (lane & 3) ^ r;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      int row = 16 * i + 4 * lw + r;
+      row = row < m ? row : m - 1;   // rows >= m only feed accumulator rows that are never stored
+      a_src[i] = a + (int64_t)row * lda + 32 * ks + 8 * a_lr;
+    }
+  }
+  // scales + zero points of one set: lanes [0, SC_LANES) fetch scales, the next Z_LANES zeros
+  const int my_set = lw % SETS;
+  const bool sc_lane = lane < Cfg::SC_LANES + Cfg::Z_LANES;
+  const char* sc_src;       // + g * sc_gstride per group
+  int64_t sc_gstride;
+  if (lane < Cfg::SC_LANES) {
+    int col = n0 + 8 * lane;
+    col = col <= n - 8 ? col : n - 8;
+    sc_src = reinterpret_cast<const char*>(scales + col);
+    sc_gstride = (int64_t)n * sizeof(T);
+  } else {
+    int zw = (n0 >> 3) + 4 * (lane - Cfg::SC_LANES);
+    zw = zw <= (n >> 3) - 4 ? zw : (n >> 3) - 4;
+    sc_src = reinterpret_cast<const char*>(qz + zw);
+    sc_gstride = (int64_t)(n >> 3) * 4;
+  }
+
+  auto issue_w = [&](int slot, int stage) {
+#ifdef STRIPE_ABLATE_DMA
+    return;
+#endif
+    const uint32_t sb = lds_base + Cfg::W_RING + slot * Cfg::W_BYTES + lw * Cfg::W_COPIES * 1024;
+#pragma unroll
+    for (int j = 0; j < Cfg::W_COPIES; ++j)
+#ifdef STRIPE_TEST_LINEAR
+      lds_dma16_nt(w_src[j] + (int64_t)stage * 16 * Cfg::BN, sb + j * 1024);
+#else
+      lds_dma16_nt(w_src[j] + (int64_t)stage * 16 * n, sb + j * 1024);
+#endif
+  };
+  auto issue_a = [&](int slot, int stage) {
+#if defined(STRIPE_ABLATE_DMA) || defined(STRIPE_NO_A)
+    return;
+#endif
+    const uint32_t sb = lds_base + Cfg::A_RING + slot * Cfg::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      lds_dma16(a_src[i] + stage * kStBK, sb + (i * 4 + lw) * 1024);
+    const int g = (stage * kStBK + my_set * (kStBK / SETS)) / group;
+    if (sc_lane) lds_dma16(sc_src + (int64_t)g * sc_gstride, sb + Cfg::A_IMG_BYTES + my_set * Cfg::SET_BYTES);
+  };
+
+  f32x4_t acc[MT][4];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+
+  if (w_loader) {
+#pragma unroll
+    for (int s = 0; s < Cfg::W_DEPTH - 1; ++s) {
+      if (s < nst) issue_w(s, stage_of(s));
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < Cfg::A_DEPTH - 1; ++s) {
+      if (s < nst) issue_a(s, stage_of(s));
+    }
+  }
+
+  // byte offset of this lane's A fragment inside a row tile, without the k-step term (see above)
+  const int a_rd = (lc >> 2) * 1024 + (lc & 3) * 256 + ((lr ^ (lc & 3)) << 4);
+  const int colw = 64 * wn + 4 * lc;       // first of this lane's 4 columns inside the stripe
+  const int ncol = n0 + colw;
+  int cur_w = 0, cur_a = 0;                // ring slots of stage `it`
+  for (int it = 0; it < nst; ++it) {
+    // stage `it` has landed once only the copies of the stages issued after it are pending
+    if (w_loader) {
+      if (it + Cfg::W_DEPTH - 2 < nst) lds_dma_wait<Cfg::W_COPIES * (Cfg::W_DEPTH - 2)>();
+      else lds_dma_wait<0>();
+    } else {
+      if (it + Cfg::A_DEPTH - 2 < nst) lds_dma_wait<Cfg::A_COPIES * (Cfg::A_DEPTH - 2)>();
+      else lds_dma_wait<0>();
+    }
+    __syncthreads();   // stage `it` is complete in LDS; everybody is done with stage it-1
+    // this wave's operands of the stage: LDS reads go out first, the copies of a later stage
+    // are issued while they are in flight
+    const char* ab = smem + Cfg::A_RING + cur_a * Cfg::A_BYTES;
+    const char* wb = smem + Cfg::W_RING + cur_w * Cfg::W_BYTES;
+    uint2 scq[Cfg::KS_PER_WAVE];
+    uint32_t zq[Cfg::KS_PER_WAVE];
+    uint4 wq[Cfg::KS_PER_WAVE];
+    uint4 af[Cfg::KS_PER_WAVE][MT];
+#pragma unroll
+    for (int q = 0; q < Cfg::KS_PER_WAVE; ++q) {
+      const int ks = wk * Cfg::KS_PER_WAVE + q;
+      const int set = ks / (4 / SETS);
+      const char* setp = ab + Cfg::A_IMG_BYTES + set * Cfg::SET_BYTES;
+      scq[q] = *reinterpret_cast<const uint2*>(setp + colw * 2);
+      zq[q] = *reinterpret_cast<const uint32_t*>(setp + 16 * Cfg::SC_LANES + (colw >> 3) * 4);
+      wq[q] = *reinterpret_cast<const uint4*>(wb + (4 * ks + lr) * Cfg::W_ROW_BYTES + colw * 4);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        af[q][i] = *reinterpret_cast<const uint4*>(ab + i * 4096 + a_rd + ((ks ^ (lc >> 2)) << 6));
+    }
+    if (w_loader) {
+      const int nxt = it + Cfg::W_DEPTH - 1;   // goes into the slot stage it-1 just vacated
+      int slot = cur_w + Cfg::W_DEPTH - 1;
+      slot = slot >= Cfg::W_DEPTH ? slot - Cfg::W_DEPTH : slot;
+      if (nxt < nst) issue_w(slot, stage_of(nxt));
+    } else {
+      const int nxt = it + Cfg::A_DEPTH - 1;
+      int slot = cur_a + Cfg::A_DEPTH - 1;
+      slot = slot >= Cfg::A_DEPTH ? slot - Cfg::A_DEPTH : slot;
+      if (nxt < nst) issue_a(slot, stage_of(nxt));
+    }
+#ifndef STRIPE_ABLATE_COMPUTE
+    // Software pipeline over the 4*KS_PER_WAVE packed words of the stage: the MFMAs of word j
+    // are issued between the dequant VALU of word j+1 (a lone wave issues a VALU op every ~8
+    // cycles and an MFMA occupies the matrix pipe for 16: back to back they do not overlap).
+    constexpr int NWORDS = 4 * Cfg::KS_PER_WAVE;
+    float scf[Cfg::KS_PER_WAVE][4], zsf[Cfg::KS_PER_WAVE][4];
+#pragma unroll
+    for (int q = 0; q < Cfg::KS_PER_WAVE; ++q) {
+      T sct[4];
+      *reinterpret_cast<uint2*>(sct) = scq[q];
+      float zp[4];
+      unpack_zeros4<ZMODE>(zq[q], ncol, zp);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        scf[q][t] = to_f32(sct[t]);
+        zsf[q][t] = -zp[t] * scf[q][t];
+      }
+    }
+    auto word_of = [&](int j) {
+      const int q = j >> 2, t = j & 3;
+      return t == 0 ? wq[q].x : (t == 1 ? wq[q].y : (t == 2 ? wq[q].z : wq[q].w));
+    };
+    uint4 bf_cur = dequant_word<T>(word_of(0), scf[0][0], zsf[0][0]);
+#pragma unroll
+    for (int j = 0; j < NWORDS; ++j) {
+      const int q = j >> 2, t = j & 3;
+      uint4 bf_nxt = bf_cur;
+      if (j + 1 < NWORDS) bf_nxt = dequant_word<T>(word_of(j + 1), scf[(j + 1) >> 2][(j + 1) & 3], zsf[(j + 1) >> 2][(j + 1) & 3]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][t] = Mfma<T>::run(af[q][i], bf_cur, acc[i][t]);
+      if (j + 1 < NWORDS) {
+        // interleave: MT groups of {1 MFMA, ceil(19/MT) VALU}
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (19 + MT - 1) / MT, 0);
+        }
+      }
+      bf_cur = bf_nxt;
+    }
+#endif
+    cur_w = cur_w + 1 == Cfg::W_DEPTH ? 0 : cur_w + 1;
+    cur_a = cur_a + 1 == Cfg::A_DEPTH ? 0 : cur_a + 1;
+  }
+
+  // ---- add the KW K-waves of each column wave through LDS (the rings are dead now) ----
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+  constexpr int kSlab = MT * 16 * 64;
+  if (wk > 0) {
+    float* dst = red + ((wk - 1) * NW + wn) * kSlab;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = i * 16 + 4 * lr + j;
+        *reinterpret_cast<float4*>(dst + row * 64 + 4 * lc) =
+            make_float4(acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]);
+      }
+    }
+  }
+  __syncthreads();
+  if (wk > 0 || ncol >= n) return;
+#pragma unroll 1
+  for (int w = 1; w < Cfg::KW; ++w) {
+    const float* src = red + ((w - 1) * NW + wn) * kSlab;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = i * 16 + 4 * lr + j;
+        const float4 v = *reinterpret_cast<const float4*>(src + row * 64 + 4 * lc);
+        acc[i][0][j] += v.x;
+        acc[i][1][j] += v.y;
+        acc[i][2][j] += v.z;
+        acc[i][3][j] += v.w;
+      }
+    }
+  }
+  float* slab = slabs + (int64_t)blockIdx.y * m * n;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = i * 16 + 4 * lr + j;
+      if (row >= m) continue;
+      if (gridDim.y == 1) {
+        const uint2 v = make_uint2(Mfma<T>::pack(acc[i][0][j], acc[i][1][j]),
+                                   Mfma<T>::pack(acc[i][2][j], acc[i][3][j]));
+        *reinterpret_cast<uint2*>(c + (int64_t)row * n + ncol) = v;
+      } else {
+        *reinterpret_cast<float4*>(slab + (int64_t)row * n + ncol) =
+            make_float4(acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]);
+      }
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+struct StripePlan {
+  int nw, sk, steps;
+  double est_us;
+};
+
+// Cost model (microseconds) behind the choice of stripe width and K split; constants from
+// /opt/skills/guides/MI355X_MICROARCH.md (per-CU LDS fill ~70 GB/s from L2, HBM ~6.5 TB/s
+// streamed, plain stores ~6 TB/s) and the kernel's ~100 VALU per wave and k-step.
+static StripePlan plan_stripe(int rows, int n, int k, int64_t ws_elems) {
+  if (const char* f = getenv("MI355X_STRIPE_FORCE")) {   // "nw,sk" (kernel experiments)
+    int nw = 2, sk = 1;
+    if (sscanf(f, "%d,%d", &nw, &sk) == 2 && (nw == 2 || nw == 4) && sk >= 1) {
+      const int stages = k / kStBK;
+      if (sk > stages) sk = stages;
+      if (sk > 1 && (int64_t)sk * rows * n > ws_elems) sk = 1;
+      const int steps = (stages + sk - 1) / sk;
+      return StripePlan{nw, (stages + steps - 1) / steps, steps, 0.0};
+    }
+  }
+  const int mt = (rows + 15) / 16;
+  const int mtt = mt <= 1 ? 1 : (mt <= 2 ? 2 : 4);
+  const int stages = k / kStBK;
+  const double wbytes = (double)n * k / 2;
+  StripePlan best{0, 1, stages, 1e30};
+  for (int nw = 2; nw <= 4; nw += 2) {
+    const int bn = 64 * nw;
+    const int stripes = (n + bn - 1) / bn;
+    const double fill = (64.0 * bn + mtt * 4096.0) / 70e3;
+    const double valu = nw * 0.17;
+    const double stage_t = fill > valu ? fill : valu;
+    const int max_sk = stages < 16 ? stages : 16;
+    for (int sk = 1; sk <= max_sk; ++sk) {
+      const int steps = (stages + sk - 1) / sk;
+      const int sk_eff = (stages + steps - 1) / steps;
+      if (sk_eff != sk) continue;
+      if (sk > 1 && (int64_t)sk * rows * n > ws_elems) continue;
+      const int wgs = stripes * sk;
+      const int rounds = (wgs + 255) / 256;
+      double t = 2.0 + rounds * steps * stage_t;
+      const double hbm = wbytes / 6.5e6;
+      if (t < hbm) t = hbm;
+      if (sk > 1) t += 3.0 + 2.0 * ((double)sk * rows * n * 4) / 5e6;
+      if (t < best.est_us) best = StripePlan{nw, sk, steps, t};
+    }
+  }
+  return best;
+}
+
+template <typename T, int MT, int NW, int ZMODE, int SETS>
+static int launch_stripe_cfg(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p) {
+  using Cfg = StripeCfg<MT, NW, SETS>;
+  auto kern = w4a16_gemm_stripe_kernel<T, MT, NW, ZMODE, SETS>;
+  static bool attr_set = false;  // one per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (e != hipSuccess) {
+      set_error("w4a16_gemm_stripe: cannot reserve %d B of LDS: %s", Cfg::LDS_BYTES,
+                hipGetErrorString(e));
+      return MI355X_EUNSUPPORTED;
+    }
+    attr_set = true;
+  }
+  const int stripes = (g.n + Cfg::BN - 1) / Cfg::BN;
+  hipLaunchKernelGGL(kern, dim3(stripes, p.sk), dim3(kStThreads), Cfg::LDS_BYTES, g.stream, c, g.ws,
+                     a, g.lda, g.qw, static_cast<const T*>(g.scales), g.qz,
+                     rows, g.n, g.k, g.group, p.steps);
+  return check_launch("w4a16_gemm_stripe");
+}
+
+template <typename T, int MT, int ZMODE, int SETS>
+static int launch_stripe_nw(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p) {
+  if (p.nw == 2) return launch_stripe_cfg<T, MT, 2, ZMODE, SETS>(g, a, c, rows, p);
+  return launch_stripe_cfg<T, MT, 4, ZMODE, SETS>(g, a, c, rows, p);
+}
+
+template <typename T, int ZMODE, int SETS>
+static int launch_stripe_mt(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p) {
+  const int mt = (rows + 15) / 16;
+  if (mt <= 1) return launch_stripe_nw<T, 1, ZMODE, SETS>(g, a, c, rows, p);
+  if (mt <= 2) return launch_stripe_nw<T, 2, ZMODE, SETS>(g, a, c, rows, p);
+  return launch_stripe_nw<T, 4, ZMODE, SETS>(g, a, c, rows, p);
+}
+
+// returns 1 when the shape / scratch is not one this path handles (caller falls back)
+template <typename T>
+static int run_stripe(const GemmArgs& g, int row0, int rows) {
+  if (rows > 64 || g.k % kStBK != 0 || g.n % 64 != 0 || g.n < 64) return 1;
+  int sets;
+  if (g.group % 128 == 0) sets = 1;
+  else if (g.group == 64) sets = 2;
+  else if (g.group == 32) sets = 4;
+  else return 1;
+  if ((reinterpret_cast<uintptr_t>(g.qw) & 15) || (reinterpret_cast<uintptr_t>(g.scales) & 15) ||
+      (reinterpret_cast<uintptr_t>(g.qz) & 15))
+    return 1;
+  const T* a = static_cast<const T*>(g.a) + (int64_t)row0 * g.lda;
+  T* c = static_cast<T*>(g.c) + (int64_t)row0 * g.n;
+  int rc;
+  const StripePlan p = plan_stripe(rows, g.n, g.k, g.ws ? g.ws_elems : 0);
+  if (p.nw == 0) return 1;
+#define STRIPE_Z(SETSV)                                                              \
+  (g.zmode == kZeroAwq ? launch_stripe_mt<T, kZeroAwq, SETSV>(g, a, c, rows, p)         \
+                       : launch_stripe_mt<T, kZeroGptq, SETSV>(g, a, c, rows, p))
+  rc = sets == 1 ? STRIPE_Z(1) : (sets == 2 ? STRIPE_Z(2) : STRIPE_Z(4));
+#undef STRIPE_Z
+  if (rc) return rc;
+  if (p.sk > 1) {
+    const int64_t n4 = (int64_t)rows * g.n / 4;
+    hipLaunchKernelGGL(w4a16_sum_slabs_kernel<T>, dim3((n4 + 255) / 256), dim3(256), 0, g.stream, c,
+                       g.ws, n4, p.sk);
+    rc = check_launch("w4a16_sum_slabs");
+  }
+  return rc;
+}
+
+int w4a16_gemm_stripe_dispatch(const GemmArgs& g, int dtype, int row0, int rows) {
+  if (dtype == MI355X_BF16) return run_stripe<bf16_t>(g, row0, rows);
+  if (dtype == MI355X_F16) return run_stripe<f16_t>(g, row0, rows);
+  return 1;
+}
+
+}  // namespace mi355x

@@ -59,16 +59,16 @@ __global__ void w4_dequant_pack_kernel(T* __restrict__ packed, const uint32_t* _
 
 // ---------------------------------------------------------------- kernel 3: the GEMM
 // C[M,N] = PA . PB^T with BOTH operands pre-packed as MFMA operand images: every staging
-// transfer is a lane-linear 1 KiB global_load_lds (no VGPR staging, no address shuffles), the
-// inner loop is ds_read_b128 + MFMA only.  256 x 256 x 64 tile, 8 waves (2 x 4), each wave
-// 128 x 64; two 64-KiB LDS stages; the loads of tile t+1 are in flight during the MFMAs of tile t.
+// transfer is a lane-linear 1 KiB LDS-DMA copy (no VGPR staging, no address shuffles), the
+// inner loop is ds_read_b128 + MFMA only.  256 x 256 tile, 8 waves (2 x 4), each wave 128 x 64.
+// K advances in stages of 32 (32 KiB of LDS: 16 A pieces + 16 B pieces); kUfStages stages form
+// a ring, the copies of stage t + kUfStages - 1 are issued before the MFMAs of stage t, so up
+// to three stages (96 KiB per CU) are in flight behind the matrix pipe.  One barrier per stage.
 constexpr int kUfBM = 256;
 constexpr int kUfBN = 256;
-constexpr int kUfBK = 64;
+constexpr int kUfBK = 32;
+constexpr int kUfStages = 4;
 constexpr int kUfThreads = 512;
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 template <typename T>
 __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
@@ -76,9 +76,9 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     int k, int num_m_blocks, int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
-  // per stage: A pieces [16 mt][2 ks][64] then B pieces [16 nt][2 ks][64]  (uint4 units)
-  constexpr int kStage = 2 * 16 * 2 * 64;  // 4096 uint4 = 64 KiB
-  constexpr int kBOff = 16 * 2 * 64;
+  // per stage: A pieces [16 mt][64] then B pieces [16 nt][64]  (uint4 units)
+  constexpr int kStage = 2 * 16 * 64;  // 2048 uint4 = 32 KiB
+  constexpr int kBOff = 16 * 64;
 
   int tile;
   {
@@ -111,32 +111,32 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   const int ktiles = k / kUfBK;
   const int kt32 = k >> 5;
 
-  // staging: wave w copies A pieces 4w..4w+3 and B pieces 4w..4w+3 of each stage
-  // (piece p = (tile index p>>1, ks = p&1); consecutive kt pieces are adjacent in global memory)
-  const uint4* a_src[4];
-  const uint4* b_src[4];
+  // staging: wave w copies A pieces 2w, 2w+1 and B pieces 2w, 2w+1 of each stage
+  // (piece = 16-row tile; its successive k-steps are adjacent in global memory)
+  const uint4* a_src[2];
+  const uint4* b_src[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = wave * 4 + i;
-    int gmt = mb * 16 + (p >> 1);
+  for (int i = 0; i < 2; ++i) {
+    const int p = wave * 2 + i;
+    int gmt = mb * 16 + p;
     const int max_mt = ((m + 15) >> 4) - 1;
     gmt = gmt < max_mt ? gmt : max_mt;
-    a_src[i] = pa + ((int64_t)gmt * kt32 + (p & 1)) * 64 + lane;
-    int gnt = nb * 16 + (p >> 1);
+    a_src[i] = pa + (int64_t)gmt * kt32 * 64 + lane;
+    int gnt = nb * 16 + p;
     const int max_nt = (n >> 4) - 1;
     gnt = gnt < max_nt ? gnt : max_nt;
-    b_src[i] = pb + ((int64_t)gnt * kt32 + (p & 1)) * 64 + lane;
+    b_src[i] = pb + (int64_t)gnt * kt32 * 64 + lane;
   }
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   auto stage = [&](int buf, int kt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int p = wave * 4 + i;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(a_src[i] + (int64_t)kt * 128),
-                                       (lds_void_t*)(lds + buf * kStage + p * 64), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(b_src[i] + (int64_t)kt * 128),
-                                       (lds_void_t*)(lds + buf * kStage + kBOff + p * 64), 16, 0, 0);
+    for (int i = 0; i < 2; ++i) {
+      const int p = wave * 2 + i;
+      lds_dma16(a_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + p * 64) * 16);
+      lds_dma16(b_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + kBOff + p * 64) * 16);
     }
   };
+  constexpr int kPerStage = 4;  // copies one wave issues per stage
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -145,29 +145,36 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     for (int t = 0; t < 4; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
 
-  stage(0, 0);
-  __syncthreads();   // (emits vmcnt(0): stage 0 has landed)
+#pragma unroll
+  for (int s = 0; s < kUfStages - 1; ++s) {
+    if (s < ktiles) stage(s, s);
+  }
 
   const int frag = frag_swz(lr, lc);  // this lane's slot inside a piece
-  int cur = 0;
+  int cur = 0;                        // ring slot of stage kt
   for (int kt = 0; kt < ktiles; ++kt) {
-    if (kt + 1 < ktiles) stage(cur ^ 1, kt + 1);
-    const uint4* abuf = lds + cur * kStage + (wm * 8) * 2 * 64 + frag;
-    const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 2 * 64 + frag;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint4 bf[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) bf[t] = bbuf[(t * 2 + ks) * 64];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint4 af = abuf[(i * 2 + ks) * 64];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[i][t] = Mfma<T>::run(af, bf[t], acc[i][t]);
-      }
+    // stage kt has landed once at most the copies of the stages issued after it are pending
+    if (kt + kUfStages - 2 < ktiles) lds_dma_wait<kPerStage * (kUfStages - 2)>();
+    else lds_dma_wait<0>();
+    __syncthreads();  // everybody's share of stage kt is in LDS; all reads of stage kt-1 are done
+    {
+      const int nxt = kt + kUfStages - 1;  // goes into the slot stage kt-1 just vacated
+      int slot = cur + kUfStages - 1;
+      slot = slot >= kUfStages ? slot - kUfStages : slot;
+      if (nxt < ktiles) stage(slot, nxt);
     }
-    __syncthreads();   // all reads of `cur` done, next stage landed (vmcnt(0) + barrier)
-    cur ^= 1;
+    const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
+    const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
+    uint4 bf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bf[t] = bbuf[t * 64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint4 af = abuf[i * 64];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[i][t] = Mfma<T>::run(af, bf[t], acc[i][t]);
+    }
+    cur = cur + 1 == kUfStages ? 0 : cur + 1;
   }
 
   // ---- epilogue: lane holds 4 consecutive columns per (i, j) --------------------------------
@@ -216,7 +223,7 @@ static int run_unfused(const GemmArgs& g) {
   const int num_m_blocks = (g.m + kUfBM - 1) / kUfBM;
   const int num_n_blocks = (g.n + kUfBN - 1) / kUfBN;
   const int num_tiles = num_m_blocks * num_n_blocks;
-  const size_t smem = (size_t)2 * 4096 * sizeof(uint4);  // 128 KiB
+  const size_t smem = (size_t)kUfStages * 2048 * sizeof(uint4);  // 128 KiB
   auto kern = gemm_packed_kernel<T>;
   static bool attr_set = false;  // one flag per instantiation (T)
   if (!attr_set) {

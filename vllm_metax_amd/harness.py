@@ -90,12 +90,17 @@ class QLinear:
             self.weight = (torch.randn(k, n, device=device, generator=gen) * 0.02).to(dtype)
         self._ws = {}
 
+    _shared_ws = {}   # device -> fp32 split-K scratch shared by every layer (stream-ordered use)
+
     def _workspace(self, m: int, device):
-        ws = self._ws.get(m)
-        if ws is None:
-            # zero on entry (the reference's temp_space contract); the GEMM hands it back zeroed
-            ws = torch.zeros(m, self.n, dtype=torch.float32, device=device)
-            self._ws[m] = ws
+        """fp32 scratch for the split-K partial slabs of the decode GEMM: up to 8 slabs of
+        [m, n] (the reference passes a fresh torch.zeros temp_space per call, awq.py:140-147;
+        here one buffer per device is reused, its contents are scratch)."""
+        need = 8 * m * self.n
+        ws = QLinear._shared_ws.get(device)
+        if ws is None or ws.numel() < need:
+            ws = torch.zeros(need, dtype=torch.float32, device=device)
+            QLinear._shared_ws[device] = ws
         return ws
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
