@@ -4,6 +4,8 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 from vllm_metax_amd import _custom_ops as ops
 d = torch.device("cuda:0")
 M, K, N, g = 8192, 4096, 6144, 128
+if len(sys.argv) > 2:
+    K, N = int(sys.argv[1]), int(sys.argv[2])
 qw = torch.randint(-2**31, 2**31 - 1, (K // 8, N), dtype=torch.int32, device=d).view(N, K // 8)
 qz = torch.randint(-2**31, 2**31 - 1, (K // g, N // 8), dtype=torch.int32, device=d)
 sc = (torch.rand(K // g, N, device=d) * 4e-3 + 1e-3).to(torch.bfloat16)

@@ -5,22 +5,27 @@
 // csrc/quantization/gptq/q_gemm.cu:2354-2413) — same operands, same exact dequantisation
 // T(fma(q, s, -z*s)), fp32 accumulation.
 //
-// Regime (M = 64, Llama-3-8B layer shapes): every weight byte is read once from HBM, the
-// activations (M x K, <= 1.8 MB) are re-read by every workgroup from its XCD's L2.  What bounds a
-// CU is (a) its L2/HBM -> LDS fill rate (~70 GB/s per CU) and (b) the dequant VALU work
-// (~20 VALU per packed word).  So:
+// Regime (M = 64, Llama-3-8B layer shapes; measurements: profiles/r01_decode_gemm_notes.md): every
+// weight byte is read once from HBM, the activations (M x K, <= 1.8 MB) are re-read by every
+// workgroup from its XCD's L2.  What bounds a CU is the dequant VALU work (~96 VALU per wave and
+// k-step, the byte->float and float->bf16 converts at half rate) and its L2/HBM -> LDS fill rate.
 //   * one workgroup owns a STRIPE of BN = 64*NW columns (NW = 2 or 4 "column waves") and a
 //     contiguous K range; its 8 waves are NW column waves x KW = 8/NW K waves.  The column waves
 //     share the activation bytes of a k-step through LDS, so A traffic per weight byte is 4/NW of
 //     what a 64-column tile pays.
-//   * weights, activations (pre-tiled MFMA operand images, pack_a_kernel), scales and zero
-//     points all arrive by LDS-DMA into a ring of kStStages stages of 128 k; the copies of
-//     stage t+3 are issued before the math of stage t, nothing is staged through VGPRs and
-//     ~100 KiB per CU stay in flight.
+//   * weights, activations, scales and zero points all arrive by LDS-DMA into rings of stages of
+//     128 k (asynchronous, no VGPR staging).  A wave's DMA queue completes in issue order, so the
+//     weight ring is fed by waves 0-3 and the activation/scale ring by waves 4-7; each waits only
+//     on its own copies.  One workgroup barrier per stage.
+//   * activations are copied straight from the row-major [M, K] tensor: the LDS side of an
+//     LDS-DMA is lane-linear, so the choice of WHICH 16 bytes lane l fetches builds a
+//     bank-conflict-free MFMA operand layout on the fly (no pre-tiling pass).
 //   * K is split across workgroups only as far as needed to put ~all CUs on the weight
 //     stream; partial tiles go to fp32 slabs ws[split][M][N] with plain stores and one small
 //     kernel adds the slabs in split order and rounds to T (deterministic, no atomics: float
 //     atomics run at ~1.3 TB/s chip-wide, plain stores at ~6).
+//   * -DSTRIPE_ABLATE_COMPUTE / _DMA / STRIPE_NO_A / STRIPE_NO_NT / STRIPE_DEEP are the compile-time
+//     ablations behind the numbers in the notes (scripts/build_variant.sh); never set in the build.
 #include <cstdio>
 #include <cstdlib>
 

@@ -92,7 +92,10 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   // (a 32 x 1 strip re-streams every A panel from HBM/MALL for every column block).
   int mb, nb;
   {
-    constexpr int GM = 8;
+#ifndef UF_GM
+#define UF_GM 8
+#endif
+    constexpr int GM = UF_GM;
     const int num_n_blocks = num_tiles / num_m_blocks;
     const int group = tile / (GM * num_n_blocks);
     const int first_m = group * GM;
