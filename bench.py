@@ -11,9 +11,14 @@ through the C-ABI HIP library; decode steps are replayed from a HIP graph.
 
     value = K * 64 * 128 output tokens / wall time of K jobs (inputs resident in HBM).
 
-`--gpus N` (launched by torch.distributed.run, one rank per GPU) shards the SAME job with
+`--gpus N` (launched by torch.distributed.run, one rank per GPU, RCCL for the rendezvous, the
+barriers and the max-over-ranks clock).  Sequences are independent units of this path, so the
+default `--parallelism dp` runs one model replica per GPU, each serving its own batch of 64
+prompts with no data-path collective: per-GPU work is fixed -> "scaling": "weak", value = the
+tokens ALL ranks produced / max-over-ranks time.  `--parallelism tp` instead shards ONE job with
 tensor parallelism TP=N (heads / FFN sharded, RCCL all-reduce after o_proj and down_proj,
-all-gather of the vocab-parallel logits): total work is fixed -> "scaling": "strong".
+all-gather of the vocab-parallel logits): total work fixed -> "scaling": "strong" — the layout the
+70B/72B configs need; for an 8B model the decode GEMMs of a 1/8 shard are launch-bound.
 
 Extra objects on the JSON line: "roofline" (dominant kernel, timed live with HIP events on
 the launch stream inside the timed region), "roofline_other" (the other hot kernels),
@@ -50,6 +55,11 @@ def parse_args():
     ap.add_argument("--input-len", type=int, default=1024)
     ap.add_argument("--output-len", type=int, default=128)
     ap.add_argument("--chunk-seqs", type=int, default=8)
+    ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"],
+                    help="N > 1: dp = one model replica per GPU, each serving its own batch of "
+                         "--batch sequences (sequences are independent: no data-path collective, weak "
+                         "scaling); tp = one model sharded over the N GPUs (column/row-parallel GEMMs, "
+                         "RCCL all-reduce after o_proj / down_proj, strong scaling)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--kernel-stats", action="store_true",
@@ -140,6 +150,21 @@ def instrument(model, timer: EventTimer):
     wrap("silu_and_mul", cost_rows(2, 1))
     wrap("rotary_embedding", lambda pos, q, k, *a: (0.0, 2.0 * (q.numel() + (k.numel() if k is not None else 0)) * 2))
     wrap("reshape_and_cache", lambda key, value, *a, **k: (0.0, 4.0 * key.numel() * 2))
+
+
+def max_over_ranks(elapsed: float, device, world: int) -> float:
+    """The job is as slow as its slowest rank (contract: MAX over ranks)."""
+    if world <= 1:
+        return elapsed
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    return t.item()
+
+
+def whole_job_tokens(steps: int, batch: int, output_len: int, world: int, tp: int) -> int:
+    """Output tokens produced by ALL ranks: dp replicas each serve their own batch, a tp group
+    serves one."""
+    return steps * batch * output_len * (world if tp == 1 else 1)
 
 
 def run_job(model, tokens, args, timer=None, ttft=None):
@@ -241,12 +266,13 @@ def main():
         group = torch.distributed.group.WORLD
 
     from vllm_metax_amd import harness
-    cfg = harness.ModelConfig.llama3_8b(args.quant, tp=world) if args.model == "llama-3-8b" \
+    tp = world if args.parallelism == "tp" else 1
+    cfg = harness.ModelConfig.llama3_8b(args.quant, tp=tp) if args.model == "llama-3-8b" \
         else harness.ModelConfig.tiny(args.quant)
-    cfg.tp = world
+    cfg.tp = tp
     max_len = args.input_len + args.output_len
     model = harness.HotPathModel(cfg, args.batch, max_len, device=f"cuda:{local_rank}", seed=0,
-                                 tp_group=group)
+                                 tp_group=group if tp > 1 else None)
     model.setup_decode(args.batch, args.input_len, max_len)
     model.cfg_ctx_for_cost = 0
     model.mean_decode_len_for_cost = args.input_len + (args.output_len - 1) / 2.0 + 1
@@ -282,10 +308,7 @@ def main():
         ttft_events.append(tt)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=model.device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+    elapsed = max_over_ranks(elapsed, model.device, world)
 
     ttfts = []
     for s, tt in zip(start_ev, ttft_events):
@@ -322,7 +345,7 @@ def main():
     # HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of
     # the same kernels at the same shapes; a counter pass cannot run inside the timed region)
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath) and args.model == "llama-3-8b" and world == 1:
+    if os.path.exists(tpath) and args.model == "llama-3-8b" and tp == 1:
         with open(tpath) as f:
             traffic = json.load(f)
         for r in roofs:
@@ -335,7 +358,8 @@ def main():
 
     if rank != 0:
         return
-    out_tokens = args.steps * args.batch * args.output_len
+    replicas = world if tp == 1 else 1       # dp: every rank served its own batch
+    out_tokens = whole_job_tokens(args.steps, args.batch, args.output_len, world, tp)
     result = {
         "metric": "output tokens/sec (Llama-3-8B AWQ-int4, batch 64, 1024-in/128-out) + p50 TTFT",
         "value": round(out_tokens / elapsed, 2),
@@ -345,15 +369,16 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if tp == 1 else "strong",
         "vs_baseline": None,
         "dtype": "bf16" if args.quant != "fp8" else "fp8",
         "data": "synthetic",
         "config": {"workload": f"{cfg.name}-{args.quant} w4a16 g128: prefill {args.batch}x{args.input_len} "
                                f"in chunks of {args.chunk_seqs} seqs + {args.output_len - 1} graph-replayed "
                                f"decode steps (1 step = 1 whole job)",
-                   "batch": args.batch, "input_len": args.input_len, "output_len": args.output_len,
-                   "parallelism": f"tp{world}", "kv_block_size": 16},
+                   "batch": args.batch, "global_batch": args.batch * replicas,
+                   "input_len": args.input_len, "output_len": args.output_len,
+                   "parallelism": f"tp{world}" if tp > 1 else f"dp{world}", "kv_block_size": 16},
         "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
         "roofline": roofs[0] if roofs else None,
         "roofline_other": roofs[1:],

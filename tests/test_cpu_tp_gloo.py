@@ -135,3 +135,37 @@ def test_harness_shard_sizes():
         c = harness.ModelConfig.llama3_8b("awq", tp=tp)
         assert (c.heads // tp) * c.head_dim % c.group_size == 0
         assert (c.ffn // tp) % c.group_size == 0
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util, pathlib
+    spec = importlib.util.spec_from_file_location("bench", pathlib.Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    q.put((rank, bench.max_over_ranks(1.0 + rank, "cpu", world)))
+    dist.destroy_process_group()
+
+
+def test_dp_replica_aggregation_world2():
+    """bench.py --gpus N default (dp): whole-job tokens = all ranks' tokens, clock = slowest rank."""
+    import importlib.util, pathlib
+    import torch.multiprocessing as mp
+    spec = importlib.util.spec_from_file_location("bench", pathlib.Path(__file__).resolve().parents[1] / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.whole_job_tokens(2, 64, 128, 8, 1) == 2 * 64 * 128 * 8      # dp8: 8 replicas
+    assert bench.whole_job_tokens(2, 64, 128, 8, 8) == 2 * 64 * 128          # tp8: one job
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+    assert got == {0: 2.0, 1: 2.0}

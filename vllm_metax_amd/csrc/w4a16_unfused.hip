@@ -168,14 +168,18 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     }
     const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
     const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
-    uint4 bf[4];
+    // all 12 fragment reads of the stage go out before the first MFMA (the scheduler would
+    // otherwise pair each A read with its 4 MFMAs and expose the LDS latency 8 times per stage)
+    uint4 bf[4], af[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) bf[t] = bbuf[t * 64];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint4 af = abuf[i * 64];
+    for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[i][t] = Mfma<T>::run(af, bf[t], acc[i][t]);
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[i][t] = Mfma<T>::run(af[i], bf[t], acc[i][t]);
     }
     cur = cur + 1 == kUfStages ? 0 : cur + 1;
   }
