@@ -155,6 +155,17 @@ int mi355x_fused_add_rms_norm(void* input, void* residual, const void* weight,
                               float epsilon, int num_tokens, int hidden_size,
                               int64_t input_stride, int dtype, mi355x_stream stream);
 
+/* MI355X-side fusion (no reference op): fused_add_rms_norm whose input row is the still
+ * unreduced output of the preceding decode GEMM, x = T(slab[0] + .. + slab[sk-1]) with fp32 slabs
+ * [sk][num_tokens][hidden] as left by mi355x_awq_gemm_deferred.
+ * Bit-identical to gemm + fused_add_rms_norm (same summation order, same rounding points); saves
+ * the slab-sum launch.  sk == 0: plain fused_add_rms_norm on `input`.  `input` receives the
+ * normalised rows either way.  ref semantics: csrc/layernorm_kernels.cu:54-138. */
+int mi355x_fused_add_rms_norm_slabs(void* input, void* residual, const void* weight,
+                                    const float* slabs, int sk, float epsilon, int num_tokens,
+                                    int hidden_size, int64_t input_stride, int dtype,
+                                    mi355x_stream stream);
+
 /* ref: csrc/layernorm_quant_kernels.cu:168-194, :210-249. out is float8_e4m3fn. */
 int mi355x_rms_norm_static_fp8_quant(void* out, const void* input, const void* weight,
                                      const float* scale, float epsilon, int num_tokens,
@@ -241,6 +252,16 @@ int mi355x_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void*
                     const uint32_t* qzeros, float* workspace, int64_t workspace_elems,
                     void* dq_workspace, int64_t dq_workspace_bytes, int m, int n, int k,
                     int group_size, int64_t lda, int dtype, mi355x_stream stream);
+
+/* awq_gemm whose split-K reduction is left to the consumer: identical arguments plus `sk_out`.
+ * If the kernel split K (M <= 64, workspace given) the fp32 partial slabs [sk][m][n] stay in
+ * `workspace`, `c` is NOT written and *sk_out = sk (>= 2); otherwise `c` holds the result and
+ * *sk_out = 0.  Consumer: mi355x_fused_add_rms_norm_slabs. */
+int mi355x_awq_gemm_deferred(void* c, const void* a, const uint32_t* qweight, const void* scales,
+                             const uint32_t* qzeros, float* workspace, int64_t workspace_elems,
+                             void* dq_workspace, int64_t dq_workspace_bytes, int m, int n, int k,
+                             int group_size, int64_t lda, int dtype, int* sk_out,
+                             mi355x_stream stream);
 
 /* gptq_shuffle: in-place exllama nibble shuffle of q_weight [K/8, N]; with q_perm
  * (int32 [K]) rows are first made sequential through `scratch` (>= K/8*N words).

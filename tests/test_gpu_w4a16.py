@@ -205,3 +205,33 @@ def test_awq_gemm_linearity_full_size():
     assert (big[100:164] == 0).all()
     big2 = ops().awq_gemm((x * 2).contiguous(), q2d, qz.to(d), sc.to(d), 8, torch.empty(0), True)
     assert torch.equal(big2, big * 2)  # power-of-two scaling is exact in every rounding step
+
+
+@pytest.mark.parametrize("m,k,n", [(64, 4096, 4096), (64, 14336, 4096), (7, 1024, 768), (33, 512, 256)])
+def test_deferred_split_k_plus_norm_is_bit_identical(m, k, n):
+    """MI355X-side fusion: awq_gemm_deferred + fused_add_rms_norm_slabs must give exactly the bits
+    of awq_gemm + fused_add_rms_norm (same slab order, same rounding points), repeatedly."""
+    dtype, group = torch.bfloat16, 128
+    qw, qz, sc, _, _ = make_awq(k, n, group, dtype, seed=21)
+    d = dev()
+    q2d = ops().awq_to_gptq_4bit(qw.to(d))
+    qz, sc = qz.to(d), sc.to(d)
+    g = torch.Generator().manual_seed(22)
+    x = (torch.randn(m, k, generator=g) * 0.5).to(dtype).to(d)
+    res0 = torch.randn(m, n, generator=g).to(dtype).to(d)
+    w = (torch.rand(n, generator=g) + 0.5).to(dtype).to(d)
+    ws = torch.full((8 * m * n,), float("nan"), dtype=torch.float32, device=d)
+    ref_out = ops().awq_gemm(x, q2d, qz, sc, 8, ws, True)
+    ref_res = res0.clone()
+    ops().fused_add_rms_norm(ref_out, ref_res, w, 1e-5)
+    saw_slabs = False
+    for _ in range(5):
+        ws.fill_(float("nan"))
+        out, sk = ops().awq_gemm_deferred(x, q2d, qz, sc, ws)
+        saw_slabs |= sk >= 2
+        res = res0.clone()
+        ops().fused_add_rms_norm_slabs(out, res, w, ws, sk, 1e-5)
+        assert_bit_exact(out, ref_out, "deferred norm out")
+        assert_bit_exact(res, ref_res, "deferred norm residual")
+    if (m, k, n) == (64, 4096, 4096):
+        assert saw_slabs          # the Llama-3-8B o_proj shape does split K

@@ -41,6 +41,7 @@ PROTOTYPES = {
         _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _I, _L, _L, _L, _L, _I, _P]),
     "mi355x_rms_norm": (_I, [_P, _P, _P, _F, _I, _I, _L, _I, _P]),
     "mi355x_fused_add_rms_norm": (_I, [_P, _P, _P, _F, _I, _I, _L, _I, _P]),
+    "mi355x_fused_add_rms_norm_slabs": (_I, [_P, _P, _P, _P, _I, _F, _I, _I, _L, _I, _P]),
     "mi355x_rms_norm_static_fp8_quant": (_I, [_P, _P, _P, _P, _F, _I, _I, _L, _I, _P]),
     "mi355x_fused_add_rms_norm_static_fp8_quant": (
         _I, [_P, _P, _P, _P, _P, _F, _I, _I, _L, _I, _P]),
@@ -55,6 +56,8 @@ PROTOTYPES = {
     "mi355x_awq_to_gptq_4bit": (_I, [_P, _P, _I, _I, _P]),
     "mi355x_awq_dequantize": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mi355x_awq_gemm": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _L, _I, _P]),
+    "mi355x_awq_gemm_deferred": (
+        _I, [_P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _L, _I, _P, _P]),
     "mi355x_gptq_shuffle": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mi355x_gptq_gemm": (
         _I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P]),

@@ -249,6 +249,27 @@ def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torc
     _abi.check(rc, "fused_add_rms_norm")
 
 
+def fused_add_rms_norm_slabs(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                             slabs: Optional[torch.Tensor], sk: int, epsilon: float) -> None:
+    """MI355X-side fusion: fused_add_rms_norm whose input is still the `sk` fp32 split-K slabs of
+    the preceding decode GEMM (awq_gemm_deferred); sk == 0 -> plain fused_add_rms_norm.  `input`
+    receives the normalised rows.  Bit-identical to awq_gemm + fused_add_rms_norm."""
+    _dev(input, residual, weight)
+    if not residual.is_contiguous() or not weight.is_contiguous():
+        raise RuntimeError("fused_add_rms_norm_slabs: residual and weight must be contiguous")
+    hidden = input.size(-1)
+    num_tokens = input.numel() // hidden if hidden else 0
+    in_stride = input.stride(-2) if input.dim() >= 2 else hidden
+    if sk > 0:
+        _dev(slabs)
+        if slabs.dtype != torch.float32 or slabs.numel() < sk * num_tokens * hidden:
+            raise RuntimeError("fused_add_rms_norm_slabs: slabs must be float32 [sk, tokens, hidden]")
+    rc = _abi.load().mi355x_fused_add_rms_norm_slabs(
+        _ptr(input), _ptr(residual), _ptr(weight), _ptr(slabs) if sk > 0 else None, int(sk),
+        float(epsilon), num_tokens, hidden, in_stride, _dt(input), _stream())
+    _abi.check(rc, "fused_add_rms_norm_slabs")
+
+
 def _check_fp8(out: torch.Tensor) -> None:
     if out.dtype != torch.float8_e4m3fn:
         raise RuntimeError(f"expected a float8_e4m3fn output, got {out.dtype}")
@@ -475,6 +496,28 @@ def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
                                      m, n, k, group, input.stride(0), _dt(input), _stream())
     _abi.check(rc, "awq_gemm")
     return out
+
+
+def awq_gemm_deferred(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
+                      scales: torch.Tensor, temp_space: torch.Tensor):
+    """awq_gemm that may leave its split-K reduction to the consumer: returns (out, sk).  sk >= 2:
+    the result is still `sk` fp32 slabs [sk, M, N] at the start of temp_space and `out` is
+    unwritten (pass both to fused_add_rms_norm_slabs); sk == 0: `out` holds the result."""
+    _dev(input, qweight, qzeros, scales, temp_space)
+    if input.dim() != 2 or input.stride(1) != 1:
+        raise RuntimeError("awq_gemm_deferred: input must be [M, K] with unit inner stride")
+    m, k = input.shape
+    n = qweight.size(0)
+    group = k // scales.size(0)
+    out = torch.empty((m, n), dtype=input.dtype, device=input.device)
+    dq = _dq_scratch(m, n, k, input.device)
+    sk = ctypes.c_int(0)
+    rc = _abi.load().mi355x_awq_gemm_deferred(
+        _ptr(out), _ptr(input), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(temp_space),
+        temp_space.numel(), _ptr(dq), dq.numel() if dq is not None else 0, m, n, k, group,
+        input.stride(0), _dt(input), ctypes.byref(sk), _stream())
+    _abi.check(rc, "awq_gemm_deferred")
+    return out, int(sk.value)
 
 
 def gptq_shuffle(q_weight: torch.Tensor, q_perm: torch.Tensor, bit: int) -> None:

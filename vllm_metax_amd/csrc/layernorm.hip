@@ -25,7 +25,10 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
                                 const float* __restrict__ scale_in,   // static scale
                                 float* __restrict__ scales_out,       // dynamic scales
                                 const float* __restrict__ scale_ub, float epsilon,
-                                int hidden_size) {
+                                int hidden_size,
+                                // optional: the input row is T(slab[0] + .. + slab[sk-1]) (fp32
+                                // split-K partials of the preceding GEMM, see mi355x_*_gemm_deferred)
+                                const float* __restrict__ slabs, int sk, int64_t slab_stride) {
   __shared__ float red[16];
   __shared__ float s_bcast;
   const int64_t row = blockIdx.x;
@@ -42,7 +45,23 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
     if (idx < hidden_size) {
       T iv[V];
       T rv[V];
-      if constexpr (V > 1) {
+      if (slabs != nullptr) {
+        // same arithmetic as w4a16_sum_slabs_kernel: fp32 sum in slab order, one rounding to T
+        float acc[V];
+        const float* sp = slabs + row * hidden_size + idx;
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = sp[j];
+        for (int s2 = 1; s2 < sk; ++s2) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += sp[(int64_t)s2 * slab_stride + j];
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) iv[j] = from_f32<T>(acc[j]);
+        if (res_row) {
+          if constexpr (V > 1) *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res_row + idx);
+          else rv[0] = res_row[idx];
+        }
+      } else if constexpr (V > 1) {
         *reinterpret_cast<uint4*>(iv) = *reinterpret_cast<const uint4*>(in_row + idx);
         if (res_row) *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res_row + idx);
       } else {
@@ -153,7 +172,8 @@ template <typename T, bool FUSED_ADD, int OUT>
 static int launch_norm(void* out, T* input, int64_t input_stride, T* residual,
                        const T* weight, const float* scale_in, float* scales_out,
                        const float* scale_ub, float eps, int num_tokens, int hidden,
-                       hipStream_t s, const char* name) {
+                       hipStream_t s, const char* name, const float* slabs = nullptr, int sk = 0,
+                       int64_t slab_stride = 0) {
   constexpr int V = 16 / sizeof(T);
   const bool vec = (hidden % V == 0) && (input_stride % V == 0) && al16(input) &&
                    al16(weight) && (!residual || al16(residual)) &&
@@ -174,7 +194,7 @@ static int launch_norm(void* out, T* input, int64_t input_stride, T* residual,
 #define LAUNCH_NORM(VV, CC)                                                              \
   hipLaunchKernelGGL((rms_norm_kernel<T, VV, CC, FUSED_ADD, OUT>), grid, block, 0, s, out, \
                      input, input_stride, residual, weight, scale_in, scales_out,         \
-                     scale_ub, eps, hidden)
+                     scale_ub, eps, hidden, slabs, sk, slab_stride)
   if (vec) {
     if (c <= 1) LAUNCH_NORM(V, 1);
     else if (c <= 2) LAUNCH_NORM(V, 2);
@@ -220,6 +240,27 @@ int mi355x_fused_add_rms_norm(void* input, void* residual, const void* weight,
         nullptr, static_cast<scalar_t*>(input), input_stride, static_cast<scalar_t*>(residual),
         static_cast<const scalar_t*>(weight), nullptr, nullptr, nullptr, epsilon, num_tokens,
         hidden_size, static_cast<hipStream_t>(stream), "fused_add_rms_norm");
+  });
+}
+
+int mi355x_fused_add_rms_norm_slabs(void* input, void* residual, const void* weight,
+                                    const float* slabs, int sk, float epsilon, int num_tokens,
+                                    int hidden_size, int64_t input_stride, int dtype,
+                                    mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && hidden_size > 0 && sk >= 0, MI355X_EINVAL,
+                 "fused_add_rms_norm_slabs: bad sizes");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(input && residual && weight, MI355X_EINVAL,
+                 "fused_add_rms_norm_slabs: null pointer");
+  MI355X_REQUIRE(sk == 0 || (slabs && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 &&
+                             hidden_size % 8 == 0),
+                 MI355X_EINVAL, "fused_add_rms_norm_slabs: slabs must be 16-byte aligned, hidden %% 8 == 0");
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    return launch_norm<scalar_t, true, kOutT>(
+        nullptr, static_cast<scalar_t*>(input), input_stride, static_cast<scalar_t*>(residual),
+        static_cast<const scalar_t*>(weight), nullptr, nullptr, nullptr, epsilon, num_tokens,
+        hidden_size, static_cast<hipStream_t>(stream), "fused_add_rms_norm_slabs",
+        sk > 0 ? slabs : nullptr, sk, (int64_t)num_tokens * hidden_size);
   });
 }
 

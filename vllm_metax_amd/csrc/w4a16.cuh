@@ -170,6 +170,7 @@ struct GemmArgs {
   int64_t lda;
   int zmode;
   hipStream_t stream;
+  int* defer_sk = nullptr;   // non-null: leave split-K slabs unreduced, report their count here
 };
 
 

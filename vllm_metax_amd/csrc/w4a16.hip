@@ -516,6 +516,22 @@ int mi355x_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void*
   return MI355X_DISPATCH_HALF(dtype, [&] { return run_gemm_t<scalar_t>(g, dtype); });
 }
 
+int mi355x_awq_gemm_deferred(void* c, const void* a, const uint32_t* qweight, const void* scales,
+                             const uint32_t* qzeros, float* workspace, int64_t workspace_elems,
+                             void* dq_workspace, int64_t dq_workspace_bytes, int m, int n, int k,
+                             int group_size, int64_t lda, int dtype, int* sk_out,
+                             mi355x_stream stream) {
+  MI355X_REQUIRE(sk_out != nullptr, MI355X_EINVAL, "awq_gemm_deferred: sk_out is null");
+  *sk_out = 0;
+  GemmArgs g{c, a, qweight, scales, qzeros, workspace, workspace_elems, dq_workspace,
+             dq_workspace_bytes, m, n, k, group_size, lda, kZeroAwq,
+             static_cast<hipStream_t>(stream)};
+  g.defer_sk = sk_out;
+  int rc = validate_gemm(g, "awq_gemm_deferred");
+  if (rc || m == 0) return rc;
+  return MI355X_DISPATCH_HALF(dtype, [&] { return run_gemm_t<scalar_t>(g, dtype); });
+}
+
 int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,
                      const uint32_t* qzeros, const void* scales, const int* g_idx,
                      void* perm_space, float* workspace, int64_t workspace_elems,

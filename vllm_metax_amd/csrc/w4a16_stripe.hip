@@ -469,6 +469,10 @@ static int run_stripe(const GemmArgs& g, int row0, int rows) {
   rc = sets == 1 ? STRIPE_Z(1) : (sets == 2 ? STRIPE_Z(2) : STRIPE_Z(4));
 #undef STRIPE_Z
   if (rc) return rc;
+  if (p.sk > 1 && g.defer_sk != nullptr && row0 == 0 && rows == g.m) {
+    *g.defer_sk = p.sk;   // the consumer adds the slabs (mi355x_fused_add_rms_norm_slabs)
+    return MI355X_OK;
+  }
   if (p.sk > 1) {
     const int64_t n4 = (int64_t)rows * g.n / 4;
     hipLaunchKernelGGL(w4a16_sum_slabs_kernel<T>, dim3((n4 + 255) / 256), dim3(256), 0, g.stream, c,

@@ -122,6 +122,16 @@ class QLinear:
             return out
         return torch.matmul(x, self.weight)
 
+    def deferred(self, x: torch.Tensor):
+        """(out, slabs, sk): like __call__, but a decode-sized AWQ GEMM may leave its split-K
+        slabs unreduced for ops.fused_add_rms_norm_slabs (sk == 0: `out` is final)."""
+        m = x.shape[0]
+        if self.quant == "awq" and m <= 64:
+            ws = self._workspace(m, x.device)
+            out, sk = ops.awq_gemm_deferred(x, self.qweight, self.qzeros, self.scales, ws)
+            return out, ws, sk
+        return self(x), None, 0
+
     def weight_bytes(self) -> int:
         if self.quant in ("awq", "gptq"):
             return self.k * self.n // 2 + (self.k // self.group) * self.n * 2 \
@@ -196,15 +206,19 @@ class HotPathModel:
         return blk * self.BLOCK + (positions % self.BLOCK)
 
     def _layer(self, i: int, x: torch.Tensor, residual: Optional[torch.Tensor],
-               positions: torch.Tensor, slots: torch.Tensor, attn_fn):
+               positions: torch.Tensor, slots: torch.Tensor, attn_fn, pending=(None, 0),
+               defer: bool = False):
+        """`pending` = (slabs, sk) when x is still the unreduced output of the previous layer's
+        down_proj (tp == 1 decode): the fused norm adds the slabs itself."""
         L = self.layers[i]
         cfg = self.cfg
+        fuse = defer and self.cfg.tp == 1   # with tp > 1 the all-reduce sits between GEMM and norm
         if residual is None:
             residual = x.clone()
             h = torch.empty_like(x)
             ops.rms_norm(h, x, L.ln1, cfg.eps)
         else:
-            ops.fused_add_rms_norm(x, residual, L.ln1, cfg.eps)
+            ops.fused_add_rms_norm_slabs(x, residual, L.ln1, pending[0], pending[1], cfg.eps)
             h = x
         qkv = L.qkv(h)
         q = qkv[:, :L.q_size]
@@ -214,16 +228,23 @@ class HotPathModel:
         ops.reshape_and_cache(k.view(-1, L.kv_heads, cfg.head_dim), v.view(-1, L.kv_heads, cfg.head_dim),
                               self.k_cache[i], self.v_cache[i], slots, "auto")
         attn = attn_fn(i, q.view(-1, L.q_heads, cfg.head_dim))
-        o = self._all_reduce(L.o(attn.view(-1, L.q_size)))
-        ops.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
+        if fuse:
+            o, slabs, sk = L.o.deferred(attn.view(-1, L.q_size))
+            ops.fused_add_rms_norm_slabs(o, residual, L.ln2, slabs, sk, cfg.eps)
+        else:
+            o = self._all_reduce(L.o(attn.view(-1, L.q_size)))
+            ops.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
         gu = L.gate_up(o)
         act = torch.empty(gu.shape[0], L.ffn, dtype=gu.dtype, device=gu.device)
         ops.silu_and_mul(act, gu)
+        if fuse:
+            out, slabs, sk = L.down.deferred(act)
+            return out, residual, (slabs, sk)
         out = self._all_reduce(L.down(act))
-        return out, residual
+        return out, residual, (None, 0)
 
-    def _logits_argmax(self, x: torch.Tensor, residual: torch.Tensor) -> torch.Tensor:
-        ops.fused_add_rms_norm(x, residual, self.final_norm, self.cfg.eps)
+    def _logits_argmax(self, x: torch.Tensor, residual: torch.Tensor, pending=(None, 0)) -> torch.Tensor:
+        ops.fused_add_rms_norm_slabs(x, residual, self.final_norm, pending[0], pending[1], self.cfg.eps)
         logits = torch.matmul(x, self.lm_head)
         if self.tp_group is not None and self.cfg.tp > 1:
             parts = [torch.empty_like(logits) for _ in range(self.cfg.tp)]
@@ -255,7 +276,7 @@ class HotPathModel:
             return out
 
         for i in range(self.cfg.layers):
-            x, residual = self._layer(i, x, residual, pos, slots, attn_fn)
+            x, residual, _ = self._layer(i, x, residual, pos, slots, attn_fn)
         last = (cu[1:] - 1).long()
         return self._logits_argmax(x[last].contiguous(), residual[last].contiguous())
 
@@ -293,9 +314,11 @@ class HotPathModel:
                                    self.d_seq_lens, self.BLOCK, self.d_max_seq_len, None, "auto")
             return out
 
+        pending = (None, 0)
         for i in range(self.cfg.layers):
-            x, residual = self._layer(i, x, residual, self.d_positions, slots, attn_fn)
-        nxt = self._logits_argmax(x, residual)
+            x, residual, pending = self._layer(i, x, residual, self.d_positions, slots, attn_fn,
+                                               pending, defer=True)
+        nxt = self._logits_argmax(x, residual, pending)
         self.d_tokens.copy_(nxt)
         self.d_positions.add_(1)
         self.d_seq_lens.add_(1)
