@@ -280,6 +280,26 @@ int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,
                      void* dq_workspace, int64_t dq_workspace_bytes, int m, int n, int k, int bit,
                      int group_size, int dtype, mi355x_stream stream);
 
+/* ------------------------------------------------------ decode-step fusions --
+ * MI355X-side fusions without a reference op of their own; each is bit-identical to the sequence
+ * of reference ops it replaces (tests/test_gpu_w4a16.py, tests/test_gpu_cache_norm_rotary.py).
+ *
+ * qkv_rope_cache: one launch for what follows the qkv projection of a decode step:
+ *   [qkv = T(slab[0] + .. + slab[sk-1]) when sk > 0: the unreduced output of
+ *    mi355x_awq_gemm_deferred, slabs [sk][num_tokens][(H + 2 KVH) * D] fp32]
+ *   rotary_embedding(positions, q, k), NeoX style, rot_dim == head_size
+ *                                        (csrc/pos_encoding_kernels.cu:10-34, :37-100)
+ *   reshape_and_cache(k, v, key_cache, value_cache, slot_mapping)   (csrc/cache_kernels.cu:203-255)
+ * qkv [num_tokens, qkv_stride] holds q | k | v per row and receives the rotated q and k (and, with
+ * slabs, v).  Caches in the x-split layout with x == 8 (2-byte dtypes), heads contiguous inside
+ * a block; *_block_stride in elements. */
+int mi355x_qkv_rope_cache(void* qkv, int64_t qkv_stride, const float* slabs, int sk,
+                          const int64_t* positions, const void* cos_sin_cache, void* key_cache,
+                          void* value_cache, const int64_t* slot_mapping, int num_tokens,
+                          int num_heads, int num_kv_heads, int head_size, int block_size, int x,
+                          int64_t key_block_stride, int64_t value_block_stride, int dtype,
+                          mi355x_stream stream);
+
 /* ----------------------------------------------------------------- fp8 GEMM --
  * out[M,N] (bf16/f16) = (a_scales . a[M,K] e4m3fn row-major) x
  *                       (b_scales . b[K,N] e4m3fn COLUMN-major, ldb = b.stride(1))

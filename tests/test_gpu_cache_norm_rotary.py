@@ -342,3 +342,44 @@ def test_silu_and_mul(dtype, d_, tokens):
         # expf vs torch.exp can differ by an fp32 ulp -> rare 1-ulp flips of T(silu(x)),
         # which the following T*T product can turn into 2 ulp of the output
         assert_mostly_exact(out, ref, 2, 2e-3, "silu_and_mul")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("sk", [0, 3])
+@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (8, 2, 64)])
+def test_qkv_rope_cache_matches_the_three_ops(dtype, sk, H, KVH, D):
+    """MI355X-side decode fusion: [slab sum +] rotary + reshape_and_cache in one launch must give
+    exactly the bits of the reference-op sequence (oracle: R.rotary_embedding / R.reshape_and_cache)."""
+    from tests.util import make_kv_cache_x
+    torch.manual_seed(3)
+    T, BS, NB, max_pos = 19, 16, 40, 4096
+    width = (H + 2 * KVH) * D
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    freqs = torch.outer(torch.arange(max_pos).float(), inv_freq)
+    cache = torch.cat([freqs.cos(), freqs.sin()], dim=-1).to(dtype)
+    positions = torch.randint(0, max_pos, (T,), dtype=torch.int64)
+    slots = torch.randperm(NB * BS)[:T].to(torch.int64)
+    slots[5] = -1                                            # padding token: no cache write
+    if sk:
+        slabs = torch.randn(sk, T, width)
+        qkv = slabs[0].clone()
+        for s in range(1, sk):
+            qkv = qkv + slabs[s]                             # fp32, slab order
+        qkv = qkv.to(dtype)
+    else:
+        slabs = None
+        qkv = torch.randn(T, width).to(dtype)
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KVH) * D], qkv[:, (H + KVH) * D:]
+    ref_q, ref_k = R.rotary_embedding(positions, q, k, D, cache, True)
+    kc, vc = make_kv_cache_x(NB, BS, KVH, D, dtype, seed=4)
+    ref_kc, ref_vc = kc.clone(), vc.clone()
+    R.reshape_and_cache(ref_k.reshape(T, KVH, D), v.reshape(T, KVH, D), ref_kc, ref_vc, slots)
+    d = dev()
+    qkv_d = (torch.full((T, width), float("nan")).to(dtype) if sk else qkv).to(d)
+    kc_d, vc_d = kc.to(d), vc.to(d)
+    ops().qkv_rope_cache(qkv_d, slabs.to(d) if sk else None, sk, positions.to(d), cache.to(d), kc_d, vc_d,
+                         slots.to(d), H, KVH, D)
+    assert_bit_exact(qkv_d[:, :H * D].contiguous(), ref_q.contiguous(), "q")
+    assert_bit_exact(qkv_d[:, H * D:(H + KVH) * D].contiguous(), ref_k.contiguous(), "k")
+    assert_bit_exact(kc_d, ref_kc, "key_cache")
+    assert_bit_exact(vc_d, ref_vc, "value_cache")

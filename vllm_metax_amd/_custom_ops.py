@@ -498,6 +498,29 @@ def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
     return out
 
 
+def qkv_rope_cache(qkv: torch.Tensor, slabs: Optional[torch.Tensor], sk: int,
+                   positions: torch.Tensor, cos_sin_cache: torch.Tensor, key_cache: torch.Tensor,
+                   value_cache: torch.Tensor, slot_mapping: torch.Tensor, num_heads: int,
+                   num_kv_heads: int, head_size: int) -> None:
+    """MI355X-side decode fusion: [slab sum ->] NeoX rotary on q, k -> reshape_and_cache, one launch.
+    qkv [T, (H + 2 KVH) * D] is updated in place (rotated q, k); caches as reshape_and_cache."""
+    _dev(qkv, positions, cos_sin_cache, key_cache, value_cache, slot_mapping)
+    if qkv.dim() != 2 or qkv.stride(1) != 1:
+        raise RuntimeError("qkv_rope_cache: qkv must be [tokens, width] with unit inner stride")
+    if key_cache.dim() != 5 or value_cache.dim() != 4:
+        raise RuntimeError("qkv_rope_cache: caches must be in the x-split layout")
+    if positions.dtype != torch.int64 or slot_mapping.dtype != torch.int64:
+        raise RuntimeError("qkv_rope_cache: positions and slot_mapping must be int64")
+    if cos_sin_cache.dtype != qkv.dtype or cos_sin_cache.size(-1) != head_size:
+        raise RuntimeError("qkv_rope_cache: cos_sin_cache must be [max_pos, head_size] in the qkv dtype")
+    rc = _abi.load().mi355x_qkv_rope_cache(
+        _ptr(qkv), qkv.stride(0), _ptr(slabs) if sk > 0 else None, int(sk), _ptr(positions),
+        _ptr(cos_sin_cache), _ptr(key_cache), _ptr(value_cache), _ptr(slot_mapping), qkv.size(0),
+        num_heads, num_kv_heads, head_size, value_cache.size(3), key_cache.size(4),
+        key_cache.stride(0), value_cache.stride(0), _dt(qkv), _stream())
+    _abi.check(rc, "qkv_rope_cache")
+
+
 def awq_gemm_deferred(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
                       scales: torch.Tensor, temp_space: torch.Tensor):
     """awq_gemm that may leave its split-K reduction to the consumer: returns (out, sk).  sk >= 2:

@@ -117,6 +117,16 @@ __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
   *reinterpret_cast<uint4*>(p) = v.u;
 }
 
+// rotary pair in scalar_t arithmetic (ref: csrc/pos_encoding_kernels.cu:10-34): a rounding after
+// every multiply and after the add / sub, like the c10 scalar operators.
+template <typename T>
+__device__ __forceinline__ void rot_pair(T& x, T& y, T c, T s) {
+  const T xn = sub_t<T>(mul_t<T>(x, c), mul_t<T>(y, s));
+  const T yn = add_t<T>(mul_t<T>(y, c), mul_t<T>(x, s));
+  x = xn;
+  y = yn;
+}
+
 // ---- wave64 reductions -------------------------------------------------------
 // Butterfly over the lanes whose index differs in the bits of `mask_from..32`.
 __device__ __forceinline__ float wave_sum(float v) {

@@ -10,14 +10,6 @@
 
 namespace mi355x {
 
-template <typename T>
-__device__ __forceinline__ void rot_pair(T& x, T& y, T c, T s) {
-  const T xn = sub_t<T>(mul_t<T>(x, c), mul_t<T>(y, s));
-  const T yn = add_t<T>(mul_t<T>(y, c), mul_t<T>(x, s));
-  x = xn;
-  y = yn;
-}
-
 template <typename T, bool IS_NEOX, bool VEC>
 __global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions,
                                         T* __restrict__ query, T* __restrict__ key,

@@ -220,13 +220,20 @@ class HotPathModel:
         else:
             ops.fused_add_rms_norm_slabs(x, residual, L.ln1, pending[0], pending[1], cfg.eps)
             h = x
-        qkv = L.qkv(h)
-        q = qkv[:, :L.q_size]
-        k = qkv[:, L.q_size:L.q_size + L.kv_size]
-        v = qkv[:, L.q_size + L.kv_size:]
-        ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin, True)
-        ops.reshape_and_cache(k.view(-1, L.kv_heads, cfg.head_dim), v.view(-1, L.kv_heads, cfg.head_dim),
-                              self.k_cache[i], self.v_cache[i], slots, "auto")
+        if defer and x.dtype != torch.float32:
+            # decode: slab sum + rotary + cache write in one launch
+            qkv, slabs, sk = L.qkv.deferred(h)
+            ops.qkv_rope_cache(qkv, slabs, sk, positions, self.cos_sin, self.k_cache[i],
+                               self.v_cache[i], slots, L.q_heads, L.kv_heads, cfg.head_dim)
+            q = qkv[:, :L.q_size]
+        else:
+            qkv = L.qkv(h)
+            q = qkv[:, :L.q_size]
+            k = qkv[:, L.q_size:L.q_size + L.kv_size]
+            v = qkv[:, L.q_size + L.kv_size:]
+            ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin, True)
+            ops.reshape_and_cache(k.view(-1, L.kv_heads, cfg.head_dim), v.view(-1, L.kv_heads, cfg.head_dim),
+                                  self.k_cache[i], self.v_cache[i], slots, "auto")
         attn = attn_fn(i, q.view(-1, L.q_heads, cfg.head_dim))
         if fuse:
             o, slabs, sk = L.o.deferred(attn.view(-1, L.q_size))
