@@ -145,6 +145,9 @@ def instrument(model, timer: EventTimer):
 
     wrap("paged_prefill_attention", cost_prefill)
     wrap("paged_attention_v2", cost_decode)
+    wrap("paged_attention_v1",
+         lambda out, q, kc, vc, kvh, scale, bt, sl, bs, max_len, *a, **k:
+         cost_decode(out, None, None, None, q, kc, vc, kvh, scale, bt, sl, bs, max_len))
     wrap("fused_add_rms_norm", cost_rows(3, 2))
     wrap("rms_norm", cost_rows(1, 1))
     wrap("silu_and_mul", cost_rows(2, 1))

@@ -280,6 +280,17 @@ int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,
                      void* dq_workspace, int64_t dq_workspace_bytes, int m, int n, int k, int bit,
                      int group_size, int dtype, mi355x_stream stream);
 
+/* merge_attn_states: out = softmax-weighted combination of two partial
+ * attention results over disjoint KV ranges, from their log-sum-exps; lse == +inf counts as -inf.
+ * output / prefix_output / suffix_output [num_tokens, num_heads, head_size] (heads contiguous),
+ * *_lse [num_heads, num_tokens] fp32, output_lse may be NULL.  head_size %% (16/sizeof(T)) == 0.
+ * ref: csrc/attention/merge_attn_states.cu:15-87 (kernel), :133-172 (launcher);
+ *      schema csrc/torch_bindings.cpp:74-82. */
+int mi355x_merge_attn_states(void* output, float* output_lse, const void* prefix_output,
+                             const float* prefix_lse, const void* suffix_output,
+                             const float* suffix_lse, int num_tokens, int num_heads, int head_size,
+                             int dtype, mi355x_stream stream);
+
 /* ------------------------------------------------------ decode-step fusions --
  * MI355X-side fusions without a reference op of their own; each is bit-identical to the sequence
  * of reference ops it replaces (tests/test_gpu_w4a16.py, tests/test_gpu_cache_norm_rotary.py).

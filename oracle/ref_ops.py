@@ -328,6 +328,32 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     return (s.float() * b.float()).to(x.dtype)
 
 
+# ================================================================ merge_attn_states
+def merge_attn_states(prefix_output: torch.Tensor, prefix_lse: torch.Tensor,
+                      suffix_output: torch.Tensor, suffix_lse: torch.Tensor):
+    """csrc/attention/merge_attn_states.cu:43-87 restated in fp32 with its rounding points: lse ==
+    +inf -> -inf (:45-46), m = max, se = exp(lse - m), scale = se / (p_se + s_se), out =
+    fma(p_out, p_scale, fl32(s_out * s_scale)) rounded once to scalar_t (:73-76), out_lse =
+    log(p_se + s_se) + m (:84-85).  Returns (output [T,H,D], output_lse [H,T]).
+    Cross-check: the in-test torch reference tests/kernels/attention/test_merge_attn_states.py:16-45
+    (same formula, without the fma)."""
+    p_lse = prefix_lse.float().clone()
+    s_lse = suffix_lse.float().clone()
+    p_lse[torch.isinf(p_lse)] = -float("inf")
+    s_lse[torch.isinf(s_lse)] = -float("inf")
+    m = torch.maximum(p_lse, s_lse)
+    p_se = torch.exp(p_lse - m)
+    s_se = torch.exp(s_lse - m)
+    out_se = p_se + s_se
+    out_lse = torch.log(out_se) + m
+    p_scale = (p_se / out_se).t().unsqueeze(-1)          # [T, H, 1] fp32
+    s_scale = (s_se / out_se).t().unsqueeze(-1)
+    t = (suffix_output.float() * s_scale)                # fp32-rounded product
+    # fma(p, p_scale, t): p * p_scale is exact in float64 (24 + 24 bits), one rounding at the end
+    out = (prefix_output.double() * p_scale.double() + t.double()).float()
+    return out.to(prefix_output.dtype), out_lse
+
+
 # ============================================================== int4 weight-only (AWQ)
 AWQ_ORDER = [0, 2, 4, 6, 1, 3, 5, 7]       # nibble i of an AWQ word holds column AWQ_ORDER[i]
 EXL_ORDER = [0, 2, 4, 6, 1, 3, 5, 7]       # nibble p of a shuffled word holds k-row EXL_ORDER[p]

@@ -168,3 +168,26 @@ def test_oracle_pack_unpack_roundtrips(seed):
     perm = torch.randperm(64, generator=torch.Generator().manual_seed(seed)).to(torch.int32)
     assert np.array_equal(R.exllama_unpack(R.gptq_shuffle(R.gptq_pack_rows(w), perm).numpy()),
                           w[perm.numpy()])
+
+
+def test_merge_attn_states_oracle_matches_the_in_test_formula():
+    """oracle.merge_attn_states vs the plain formula of the reference's own test
+    (tests/kernels/attention/test_merge_attn_states.py:16-45): out = p*p_scale + s*s_scale with the
+    +inf -> -inf convention; they may differ only by the fma's single rounding."""
+    g = torch.Generator().manual_seed(1)
+    n, h, d = 97, 8, 64
+    p_out, s_out = torch.randn(n, h, d, generator=g), torch.randn(n, h, d, generator=g)
+    p_lse, s_lse = torch.randn(h, n, generator=g) * 3, torch.randn(h, n, generator=g) * 3
+    p_lse[0, :5] = float("inf")
+    s_lse[1, 5:9] = float("inf")
+    out, lse = R.merge_attn_states(p_out, p_lse, s_out, s_lse)
+    pl, sl = p_lse.clone(), s_lse.clone()
+    pl[pl == float("inf")] = -float("inf")
+    sl[sl == float("inf")] = -float("inf")
+    m = torch.maximum(pl, sl)
+    pe, se = torch.exp(pl - m), torch.exp(sl - m)
+    want = p_out * (pe / (pe + se)).t().unsqueeze(2) + s_out * (se / (pe + se)).t().unsqueeze(2)
+    assert torch.allclose(out, want, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(lse, torch.log(pe + se) + m, rtol=1e-6, atol=1e-7)
+    # a +inf lse removes that side entirely
+    assert torch.equal(out[:5, 0], s_out[:5, 0]) and torch.equal(out[5:9, 1], p_out[5:9, 1])

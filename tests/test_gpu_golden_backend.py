@@ -216,6 +216,16 @@ def test_torch_ops_bindings_match_ctypes_path():
     torch.ops._C_cache_ops.reshape_and_cache(key, key, kc2, vc2, slots, "auto", one, one)
     assert_bit_exact(kc1, kc2, "reshape_and_cache binding")
     assert torch.ops._C_cuda_utils.get_max_shared_memory_per_block_device_attribute(0) >= 64 * 1024
+    po, so = torch.randn(9, 4, 64, device=d).to(torch.bfloat16), torch.randn(9, 4, 64, device=d).to(torch.bfloat16)
+    pl, sl2 = torch.randn(4, 9, device=d), torch.randn(4, 9, device=d)
+    m1, m2 = torch.empty_like(po), torch.empty_like(po)
+    l1, l2 = torch.empty(4, 9, device=d), torch.empty(4, 9, device=d)
+    ops().merge_attn_states(m1, po, pl, so, sl2, l1)
+    torch.ops._C.merge_attn_states(m2, l2, po, pl, so, sl2)
+    assert_bit_exact(m1, m2, "merge_attn_states binding")
+    assert torch.equal(l1, l2)
+    torch.ops._C.merge_attn_states(m2, None, po, pl, so, sl2)        # output_lse is optional
+    assert_bit_exact(m1, m2, "merge_attn_states binding (no lse)")
 
 
 # ---------------------------------------------------------------------------- (4) end to end

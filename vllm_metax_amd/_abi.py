@@ -61,6 +61,7 @@ PROTOTYPES = {
     "mi355x_gptq_shuffle": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mi355x_gptq_gemm": (
         _I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "mi355x_merge_attn_states": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mi355x_qkv_rope_cache": (
         _I, [_P, _L, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _I, _P]),
     "mi355x_scaled_mm_fp8": (

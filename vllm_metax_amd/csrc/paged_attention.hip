@@ -28,8 +28,8 @@
 
 namespace mi355x {
 
-constexpr int kPaThreads = 256;
-constexpr int kPaWaves = kPaThreads / 64;
+constexpr int kPaThreads = 256;       // default workgroup: 4 waves
+constexpr int kPaMaxThreads = 512;    // few-workgroup launches (v1 at small batch) use 8 waves
 constexpr int kPaScratchBytes = 128;  // red[16] + s_max[4] + s_sum[4], padded
 
 template <typename T>
@@ -83,7 +83,7 @@ __device__ __forceinline__ uint4 mask_tail(uint4 v, int first_token, int seq_len
 
 // HS == 0: head size is a run-time value (any multiple of 16/sizeof(T) up to 256).
 template <typename T, int BS, int GT, int HS>
-__global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
+__global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
     float* __restrict__ exp_sums,    // [num_seqs, num_heads, P]       (partitioned only)
     float* __restrict__ max_logits,  // [num_seqs, num_heads, P]       (partitioned only)
     T* __restrict__ out,             // [num_seqs, num_heads, P, head_size]
@@ -127,6 +127,8 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int nthreads = blockDim.x;           // 256 or 512 (host: launch_pa)
+  const int nwaves = nthreads >> 6;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // all LDS lives in the dynamic region so that its base stays 16-B aligned
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
   T* probs = reinterpret_cast<T*>(logits + (size_t)GT * logits_cap);    // [GT][cap]
 
   // ---- stage q (packed scalar_t) into LDS; absent heads are zero ---------------
-  for (int i = tid; i < GT * C; i += kPaThreads) {
+  for (int i = tid; i < GT * C; i += nthreads) {
     const int g = i / C;
     const int c = i - g * C;
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
       }
     }
     // two blocks per iteration and wave -> 2*NI 16-B loads in flight per lane
-    for (int blk = start_block + wave * 2; blk < end_block; blk += kPaWaves * 2) {
+    for (int blk = start_block + wave * 2; blk < end_block; blk += nwaves * 2) {
       const bool has2 = (blk + 1) < end_block;
       const int64_t pb0 = block_table[blk];
       const int64_t pb1 = has2 ? block_table[blk + 1] : pb0;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
       }
     }
   } else {
-    for (int blk = start_block + wave; blk < end_block; blk += kPaWaves) {
+    for (int blk = start_block + wave; blk < end_block; blk += nwaves) {
       const int64_t pb = block_table[blk];
       const T* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
       float a[GT];
@@ -259,6 +261,35 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
     }
   }
 
+  // The first two V blocks of this wave are requested BEFORE the softmax: nothing in the softmax
+  // touches global memory, so these loads (and the HBM latency behind them) overlap with it.
+  constexpr int TPP0 = BS / X;
+  constexpr int DPI0 = 64 / TPP0;
+  const int tq = lane % TPP0;     // which 16-B piece (X tokens) of a V row
+  const int dsub = lane / TPP0;   // V row phase
+  auto load_v = [&](int blk, uint4 (&vv)[NIV]) {
+    const int64_t pb = block_table[blk];
+    const T* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+    const bool last = (blk == num_seq_blocks - 1);
+#pragma unroll
+    for (int i = 0; i < NIV; ++i) {
+      const int d = dsub + DPI0 * i;
+      if (d < D) {
+        uint4 v = *reinterpret_cast<const uint4*>(vp + (int64_t)d * BS + tq * X);
+        if (last) v = mask_tail<T>(v, blk * BS + tq * X, seq_len);
+        vv[i] = v;
+      } else {
+        vv[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  uint4 vpre0[NIV], vpre1[NIV];
+  if constexpr (HS != 0) {
+    const int blk = start_block + wave * 2;
+    if (blk < end_block) load_v(blk, vpre0);
+    if (blk + 1 < end_block) load_v(blk + 1, vpre1);
+  }
+
   // =========================== softmax ===========================================
 #pragma unroll
   for (int g = 0; g < GT; ++g) {
@@ -271,7 +302,7 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
   for (int g = 0; g < GT; ++g) {
     lsum[g] = 0.f;
     const float m = s_max[g];
-    for (int i = tid; i < num_tokens; i += kPaThreads) {
+    for (int i = tid; i < num_tokens; i += nthreads) {
       const float e = __expf(logits[g * logits_cap + i] - m);
       logits[g * logits_cap + i] = e;
       lsum[g] += e;
@@ -287,7 +318,7 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
 #pragma unroll
   for (int g = 0; g < GT; ++g) {
     const float inv = __fdividef(1.f, s_sum[g] + 1e-6f);
-    for (int i = tid; i < padded_tokens; i += kPaThreads) {
+    for (int i = tid; i < padded_tokens; i += nthreads) {
       const float p = (i < num_tokens) ? logits[g * logits_cap + i] * inv : 0.f;
       probs[g * logits_cap + i] = from_f32<T>(p);
     }
@@ -300,8 +331,6 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
   __syncthreads();
 
   // =========================== P.V ===============================================
-  const int tq = lane % TPP;     // which 16-B piece (X tokens) of a V row
-  const int dsub = lane / TPP;   // V row phase
   float oacc[GT][NIV];
 #pragma unroll
   for (int g = 0; g < GT; ++g) {
@@ -322,34 +351,24 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
     }
   };
 
-  auto load_v = [&](int blk, uint4 (&vv)[NIV]) {
-    const int64_t pb = block_table[blk];
-    const T* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
-    const bool last = (blk == num_seq_blocks - 1);
+  if constexpr (HS != 0) {
+    // software pipeline: the loads of iteration i+1 are issued before the math of iteration i
+    for (int blk = start_block + wave * 2; blk < end_block; blk += nwaves * 2) {
+      const bool has2 = (blk + 1) < end_block;
+      const int nb = blk + nwaves * 2;
+      uint4 n0[NIV], n1[NIV];
+      if (nb < end_block) load_v(nb, n0);
+      if (nb + 1 < end_block) load_v(nb + 1, n1);
+      pv_block(blk, vpre0);
+      if (has2) pv_block(blk + 1, vpre1);
 #pragma unroll
-    for (int i = 0; i < NIV; ++i) {
-      const int d = dsub + DPI * i;
-      if (d < D) {
-        uint4 v = *reinterpret_cast<const uint4*>(vp + (int64_t)d * BS + tq * X);
-        if (last) v = mask_tail<T>(v, blk * BS + tq * X, seq_len);
-        vv[i] = v;
-      } else {
-        vv[i] = make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < NIV; ++i) {
+        vpre0[i] = n0[i];
+        vpre1[i] = n1[i];
       }
     }
-  };
-
-  if constexpr (HS != 0) {
-    for (int blk = start_block + wave * 2; blk < end_block; blk += kPaWaves * 2) {
-      uint4 v0[NIV], v1[NIV];
-      const bool has2 = (blk + 1) < end_block;
-      load_v(blk, v0);
-      if (has2) load_v(blk + 1, v1);
-      pv_block(blk, v0);
-      if (has2) pv_block(blk + 1, v1);
-    }
   } else {
-    for (int blk = start_block + wave; blk < end_block; blk += kPaWaves) {
+    for (int blk = start_block + wave; blk < end_block; blk += nwaves) {
       uint4 v0[NIV];
       load_v(blk, v0);
       pv_block(blk, v0);
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
 
   // cross-wave sum through LDS (reuses the logits region)
   __syncthreads();
-  float* osm = logits;  // [kPaWaves][GT][D]
+  float* osm = logits;  // [nwaves][GT][D]
   if (tq == 0) {
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
@@ -380,12 +399,11 @@ __global__ __launch_bounds__(kPaThreads) void paged_attention_kernel(
     }
   }
   __syncthreads();
-  for (int i = tid; i < nheads * D; i += kPaThreads) {
+  for (int i = tid; i < nheads * D; i += nthreads) {
     const int g = i / D;
     const int d = i - g * D;
     float acc = 0.f;
-#pragma unroll
-    for (int w = 0; w < kPaWaves; ++w) acc += osm[(w * GT + g) * D + d];
+    for (int w = 0; w < nwaves; ++w) acc += osm[(w * GT + g) * D + d];
     const int64_t o = (((int64_t)seq * num_heads + head0 + g) * num_parts + part) * D + d;
     out[o] = from_f32<T>(acc);
   }
@@ -457,7 +475,7 @@ struct PaArgs {
 
 template <typename T, int BS, int GT, int HS>
 static int launch_pa_inst(const PaArgs& a, int tiles, int num_parts, int logits_cap,
-                          size_t smem) {
+                          size_t smem, int threads) {
   auto kern = paged_attention_kernel<T, BS, GT, HS>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -469,7 +487,7 @@ static int launch_pa_inst(const PaArgs& a, int tiles, int num_parts, int logits_
   }
   dim3 grid(a.num_kv_heads * tiles, a.num_seqs, num_parts);
   T* dst = static_cast<T*>(a.partition_size > 0 ? a.tmp_out : a.out);
-  hipLaunchKernelGGL(kern, grid, dim3(kPaThreads), smem, a.stream, a.exp_sums, a.max_logits, dst,
+  hipLaunchKernelGGL(kern, grid, dim3(threads), smem, a.stream, a.exp_sums, a.max_logits, dst,
                      static_cast<const T*>(a.query), static_cast<const T*>(a.key_cache),
                      static_cast<const T*>(a.value_cache), a.num_heads, a.num_kv_heads,
                      a.head_size, a.scale, a.block_tables, a.seq_lens,
@@ -487,7 +505,14 @@ static int launch_pa_bs(const PaArgs& a) {
   const int padded_len = ((a.max_seq_len + BS - 1) / BS) * BS;
   int logits_cap = a.partition_size > 0 ? a.partition_size : padded_len;
   // the cross-wave output buffer [waves][GT][D] aliases the logits region
-  const int min_cap = kPaWaves * a.head_size;
+  // Few workgroups (v1: one per (seq, kv head)) leave half of a CU's wave slots empty with
+  // 4-wave workgroups; 8 waves per workgroup put the same number of loads in flight per CU as the
+  // partitioned launch does (measured at 64 seqs x 8 kv heads, ctx 1088: see DESIGN.md §3).
+  const int num_parts_est =
+      a.partition_size > 0 ? (a.max_seq_len + a.partition_size - 1) / a.partition_size : 1;
+  const int64_t wgs = (int64_t)a.num_kv_heads * tiles * a.num_seqs * num_parts_est;
+  const int threads = wgs < 768 ? kPaMaxThreads : kPaThreads;
+  const int min_cap = (threads / 64) * a.head_size;
   if (logits_cap < min_cap) logits_cap = min_cap;
   logits_cap = (logits_cap + 63) & ~63;
   const size_t smem = kPaScratchBytes + (size_t)gt * 256 * sizeof(T) +
@@ -503,9 +528,9 @@ static int launch_pa_bs(const PaArgs& a) {
   if (gt == GTV) {                                                                     \
     if (fast) {                                                                        \
       if constexpr (BS == 16 && sizeof(T) == 2)                                        \
-        return launch_pa_inst<T, BS, GTV, 128>(a, tiles, num_parts, logits_cap, smem); \
+        return launch_pa_inst<T, BS, GTV, 128>(a, tiles, num_parts, logits_cap, smem, threads); \
     }                                                                                  \
-    return launch_pa_inst<T, BS, GTV, 0>(a, tiles, num_parts, logits_cap, smem);       \
+    return launch_pa_inst<T, BS, GTV, 0>(a, tiles, num_parts, logits_cap, smem, threads);       \
   }
   PA_CASE(1)
   PA_CASE(2)

@@ -100,6 +100,27 @@ void paged_attention_v2(Tensor& out, Tensor& exp_sums, Tensor& max_logits, Tenso
      "paged_attention_v2");
 }
 
+// ----------------------------------------------------------- merge_attn_states
+// ref: csrc/attention/merge_attn_states.cu:133-172 (launcher checks), schema torch_bindings.cpp:74-82
+void merge_attn_states(Tensor& output, std::optional<Tensor> output_lse, const Tensor& prefix_output,
+                       const Tensor& prefix_lse, const Tensor& suffix_output,
+                       const Tensor& suffix_lse) {
+  const int64_t head_size = output.size(2);
+  TORCH_CHECK(output.stride(-2) == head_size && output.stride(-1) == 1,
+              "output heads must be contiguous in memory");
+  TORCH_CHECK(prefix_output.stride(-2) == head_size && prefix_output.stride(-1) == 1,
+              "prefix_output heads must be contiguous in memory");
+  TORCH_CHECK(suffix_output.stride(-2) == head_size && suffix_output.stride(-1) == 1,
+              "suffix_output heads must be contiguous in memory");
+  Guard g(prefix_output);
+  ok(mi355x_merge_attn_states(
+         output.data_ptr(), output_lse.has_value() ? output_lse->data_ptr<float>() : nullptr,
+         prefix_output.data_ptr(), prefix_lse.data_ptr<float>(), suffix_output.data_ptr(),
+         suffix_lse.data_ptr<float>(), output.size(0), output.size(1), head_size, dt(output),
+         stream_of(output)),
+     "merge_attn_states");
+}
+
 // ------------------------------------------------------------------ activation
 void silu_and_mul(Tensor& out, Tensor& input) {
   TORCH_CHECK(out.is_contiguous() && input.is_contiguous());
@@ -510,6 +531,16 @@ TORCH_LIBRARY(_C, ops) {
       "    int blocksparse_vert_stride, int blocksparse_block_size,"
       "    int blocksparse_head_sliding_step) -> ()");
   ops.impl("paged_attention_v2", c10::kCUDA, &paged_attention_v2);
+
+  ops.def(
+      "merge_attn_states("
+      "    Tensor! output,"
+      "    Tensor!? output_lse,"
+      "    Tensor prefix_output,"
+      "    Tensor prefix_lse,"
+      "    Tensor suffix_output,"
+      "    Tensor suffix_lse) -> ()");
+  ops.impl("merge_attn_states", c10::kCUDA, &merge_attn_states);
 
   ops.def("silu_and_mul(Tensor! result, Tensor input) -> ()");
   ops.impl("silu_and_mul", c10::kCUDA, &silu_and_mul);

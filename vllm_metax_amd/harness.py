@@ -21,6 +21,7 @@ from typing import List, Optional
 import torch
 
 from . import _custom_ops as ops
+from .attention.backend import decode_attention
 
 
 @dataclasses.dataclass
@@ -316,9 +317,9 @@ class HotPathModel:
 
         def attn_fn(i, q3):
             out = torch.empty_like(q3)
-            ops.paged_attention_v2(out, self.d_es, self.d_ml, self.d_tmp, q3, self.k_cache[i],
-                                   self.v_cache[i], self.layers[i].kv_heads, self.scale, self.d_bt,
-                                   self.d_seq_lens, self.BLOCK, self.d_max_seq_len, None, "auto")
+            decode_attention(out, self.d_es, self.d_ml, self.d_tmp, q3, self.k_cache[i],
+                             self.v_cache[i], self.layers[i].kv_heads, self.scale, self.d_bt,
+                             self.d_seq_lens, self.BLOCK, self.d_max_seq_len)
             return out
 
         pending = (None, 0)
