@@ -64,6 +64,7 @@ constexpr int kPfD = 128;
 constexpr int kPfBS = 16;
 constexpr int kPfQTile = 128;   // query rows per workgroup
 constexpr int kPfKvTile = 32;   // keys per stage (2 cache blocks)
+constexpr int kPfStages = 3;    // LDS ring depth (16 KiB per stage)
 constexpr float kNegBig = -1.0e30f;
 
 template <typename T>
@@ -78,9 +79,15 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
   uint4* lds = reinterpret_cast<uint4*>(smem);
   constexpr int kStageVec = 4 * 4096 / 16;  // uint4 per stage (16 KiB)
 
-  const int seq = blockIdx.x / q_blocks_per_seq;
-  const int qb = blockIdx.x - seq * q_blocks_per_seq;
-  const int head = blockIdx.y;
+  // heaviest query blocks first: under the causal mask block qb needs (qb + 1) * 4 key stages, and
+  // workgroups are dispatched in blockIdx order — the long ones must not be the last to start
+  // (1-D grid: block = (reversed query block, head, sequence), sequence fastest)
+  const int num_seqs_g = (int)gridDim.x / (q_blocks_per_seq * num_heads);
+  const int per_qb = num_heads * num_seqs_g;
+  const int qb = q_blocks_per_seq - 1 - (int)blockIdx.x / per_qb;
+  const int rem = (int)blockIdx.x - (q_blocks_per_seq - 1 - qb) * per_qb;
+  const int head = rem / num_seqs_g;
+  const int seq = rem - head * num_seqs_g;
   const int q_begin = cu_seqlens_q[seq];
   const int q_len = cu_seqlens_q[seq + 1] - q_begin;
   const int m0 = qb * kPfQTile;
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lc = lane & 15;
   const int lr = lane >> 4;
 
@@ -122,36 +129,55 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
   const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
   const int num_seq_blocks = (seq_len + kPfBS - 1) / kPfBS;
 
-  // staging: thread t copies 16 B pieces t, t+256, t+512, t+768 of the stage image
-  // piece p: which = p >> 8 (0: K blk0, 1: K blk1, 2: V blk0, 3: V blk1), offset (p & 255)*16 B
-  uint4 stage_regs[4];
-  auto stage_load = [&](int tile) {
+  // staging: LDS-DMA, no registers (a register-staged prefetch was spilled to scratch by the
+  // compiler with a full vmcnt(0) wait per 16-B load: 4.7 us per stage, profiles/r01_*notes*).
+  // Stage image = [K blk0 | K blk1 | V blk0 | V blk1], 4 KiB each, copied verbatim; wave w copies
+  // bytes [1024 w, 1024 w + 1024) of each block: 4 lane-linear copies per wave and stage, into a
+  // ring of kPfStages stages (two stages in flight behind the math).
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+  // block ids of the sequence: 64 at a time in one VGPR, read back with readlane
+  int bt_reg = 0;
+  int bt_base = -64;
+  auto block_id = [&](int blk) {
+    if (blk >= bt_base + 64 || blk < bt_base) {
+      bt_base = blk & ~63;
+      const int i = bt_base + lane;
+      bt_reg = block_table[i < num_seq_blocks ? i : num_seq_blocks - 1];
+    }
+    return (int64_t)__builtin_amdgcn_readlane(bt_reg, blk - bt_base);
+  };
+  auto stage_issue = [&](int slot, int tile) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int blk = tile * 2 + (i & 1);
       blk = blk < num_seq_blocks ? blk : num_seq_blocks - 1;
-      const int64_t pb = block_table[blk];
+      const int64_t pb = block_id(blk);
       const T* base = (i < 2 ? k_cache : v_cache) + pb * kv_block_stride +
                       (int64_t)kv_head * kv_head_stride;
-      stage_regs[i] = *reinterpret_cast<const uint4*>(base + tid * 8);
+      lds_dma16(base + wave * 512 + lane * 8, lds_base + slot * (kStageVec * 16) + i * 4096 + wave * 1024);
     }
   };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lds[buf * kStageVec + i * 256 + tid] = stage_regs[i];
-  };
 
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
+  stage_issue(0, 0);
+  if (num_tiles > 1) stage_issue(1, 1);
 
+  const float sl2 = scale * 1.4426950408889634f;   // softmax scale in log2 units
+  // every key <= this index is visible to EVERY query row of the wave (and is a real key)
+  const int wave_limit_lo = min(ctx + m0 + wave * 32, seq_len - 1);
   // the wave's first query row decides which tiles it can skip entirely (causal)
   const int wave_q_hi = ctx + m0 + wave * 32 + 31;  // last key any row of this wave may see
 
-  int cur = 0;
+  int cur = 0;   // ring slot of `tile`
   for (int tile = 0; tile < num_tiles; ++tile) {
-    const bool has_next = (tile + 1) < num_tiles;
-    if (has_next) stage_load(tile + 1);
+    // stage `tile` has landed once only the copies of the next stage are pending
+    if (tile + 1 < num_tiles) lds_dma_wait<4>();
+    else lds_dma_wait<0>();
+    __syncthreads();   // everybody's share of stage `tile` is in LDS; stage tile-1 is dead
+    if (tile + 2 < num_tiles) {
+      int slot = cur + 2;
+      slot = slot >= kPfStages ? slot - kPfStages : slot;
+      stage_issue(slot, tile + 2);
+    }
 
     const int t0 = tile * kPfKvTile;
     if (t0 <= wave_q_hi) {
@@ -171,41 +197,53 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
         }
       }
       // ---- online softmax per query column ------------------------------------------
+      // Scores stay in raw (unscaled) units; the softmax scale and log2(e) are folded into one
+      // fma in front of v_exp_f32 (2^x): p = 2^(s*c - m*c), c = scale*log2(e).  Masking costs VALU
+      // only on tiles that reach past the wave's first visible-key limit (the diagonal / tail);
+      // the accumulator rescale is skipped when no lane's running maximum moved (alpha == 1).
       uint4 pfrag[2];
+      const bool need_mask = (t0 + kPfKvTile - 1) > wave_limit_lo;
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        const int limit = min(ctx + qrow[qt], seq_len - 1);  // last visible key of this row
         float v[8];
-        float tmax = kNegBig;
+        if (need_mask) {
+          const int limit = min(ctx + qrow[qt], seq_len - 1);  // last visible key of this row
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+          for (int b = 0; b < 2; ++b) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int key = t0 + 16 * b + 4 * lr + j;
-            const float x = key <= limit ? s[b][qt][j] * scale : kNegBig;
-            v[b * 4 + j] = x;
-            tmax = fmaxf(tmax, x);
+            for (int j = 0; j < 4; ++j) {
+              const int key = t0 + 16 * b + 4 * lr + j;
+              v[b * 4 + j] = key <= limit ? s[b][qt][j] : kNegBig;   // (also drops NaN of dead keys)
+            }
+          }
+        } else {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[b * 4 + j] = s[b][qt][j];
           }
         }
+        float tmax = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])),
+                           fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun[qt], tmax);
-        const float alpha = __expf(mrun[qt] - mnew);
+        const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * sl2);
         mrun[qt] = mnew;
-        float psum = 0.f;
+        const float mc = -mnew * sl2;
         float p[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          p[i] = v[i] > 0.5f * kNegBig ? __expf(v[i] - mnew) : 0.f;
-          psum += p[i];
-        }
+        for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(fmaf(v[i], sl2, mc));
+        const float psum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         lrun[qt] = lrun[qt] * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-          oacc[qt][dt][0] *= alpha;
-          oacc[qt][dt][1] *= alpha;
-          oacc[qt][dt][2] *= alpha;
-          oacc[qt][dt][3] *= alpha;
+          for (int dt = 0; dt < 8; ++dt) {
+            oacc[qt][dt][0] *= alpha;
+            oacc[qt][dt][1] *= alpha;
+            oacc[qt][dt][2] *= alpha;
+            oacc[qt][dt][3] *= alpha;
+          }
         }
         pfrag[qt].x = MfmaQK<T>::pack(p[0], p[1]);
         pfrag[qt].y = MfmaQK<T>::pack(p[2], p[3]);
@@ -228,9 +266,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
         for (int qt = 0; qt < 2; ++qt) oacc[qt][dt] = MfmaQK<T>::run(vf, pfrag[qt], oacc[qt][dt]);
       }
     }
-    if (has_next) stage_store(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    cur = cur + 1 == kPfStages ? 0 : cur + 1;
   }
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ----------------------------------------------
@@ -342,8 +378,8 @@ extern "C" int mi355x_paged_prefill_attention(
                     kv_head_stride % 8 == 0;
   if (fast) {
     const int q_blocks = (max_query_len + kPfQTile - 1) / kPfQTile;
-    dim3 grid(num_seqs * q_blocks, num_heads), block(256);
-    const size_t smem = 2 * 4 * 4096;
+    dim3 grid(num_seqs * q_blocks * num_heads), block(256);
+    const size_t smem = (size_t)kPfStages * 4 * 4096;   // ring of 16-KiB stages
     return MI355X_DISPATCH_HALF(dtype, [&] {
       hipLaunchKernelGGL(paged_prefill_d128_kernel<scalar_t>, grid, block, smem, s,
                          static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query),
