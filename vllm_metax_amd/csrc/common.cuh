@@ -53,6 +53,20 @@ __device__ __forceinline__ void lds_dma16(const void* gptr, uint32_t lds_base) {
                : "v"(gptr), "s"(lds_base)
                : "memory");  // (M0 is reserved: the compiler never keeps a value in it)
 }
+// same copy, source = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit byte offset: no 64-bit
+// VGPR address and no 64-bit VALU add per copy (the base advances on the scalar unit)
+__device__ __forceinline__ void lds_dma16_s(const void* sbase, uint32_t voff, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_base)
+               : "memory");
+}
+__device__ __forceinline__ void lds_dma16_s_nt(const void* sbase, uint32_t voff, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+               :
+               : "v"(voff), "s"(sbase), "s"(lds_base)
+               : "memory");
+}
 template <int N>
 __device__ __forceinline__ void lds_dma_wait() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");

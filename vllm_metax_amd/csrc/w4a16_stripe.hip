@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
   const bool w_loader = wave < 4;
   const int lw = wave & 3;
   // weights: piece p = 1 KiB = 4/NW packed rows of the stripe; loader lw copies pieces lw*NW ..
-  const uint32_t* w_src[Cfg::W_COPIES];
+  uint32_t w_off[Cfg::W_COPIES];   // byte offset from qw + stage * 16 * n
   {
     constexpr int RPP = 4 / NW;          // rows per piece
     constexpr int LPR = 64 / RPP;        // lanes per row
@@ -131,10 +131,7 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
       const int r = p * RPP + lane / LPR;
       int col = n0 + 4 * (lane % LPR);
       col = col <= n - 4 ? col : n - 4;
-      w_src[j] = qw + (int64_t)r * n + col;
-#ifdef STRIPE_TEST_LINEAR
-      w_src[j] = qw + (int64_t)blockIdx.x * (k / 8) * Cfg::BN + (int64_t)p * 256 + lane * 4;
-#endif
+      w_off[j] = (uint32_t)(((int64_t)r * n + col) * 4);
     }
   }
   // activations: loader lw copies the 4 k-step images of row tile i for i = 0..MT-1, k-step lw
@@ -146,14 +143,14 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
   // like a plain copy); the two XORs make the 16 lanes of every ds_read_b128 lane group
   // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ..) hit 16 different bank quads when lane (lr, lc)
   // reads row lc, k-group lr of one k-step — the MFMA A operand, conflict-free.
-  const T* a_src[MT];
+  uint32_t a_off[MT];   // byte offset from a + stage * 128
   {
     const int r = lane >> 4, ks = ((lane >> 2) & 3) ^ lw, a_lr = (lane & 3) ^ r;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       int row = 16 * i + 4 * lw + r;
       row = row < m ? row : m - 1;   // rows >= m only feed accumulator rows that are never stored
-      a_src[i] = a + (int64_t)row * lda + 32 * ks + 8 * a_lr;
+      a_off[i] = (uint32_t)(((int64_t)row * lda + 32 * ks + 8 * a_lr) * sizeof(T));
     }
   }
   // scales + zero points of one set: lanes [0, SC_LANES) fetch scales, the next Z_LANES zeros
@@ -180,11 +177,7 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
     const uint32_t sb = lds_base + Cfg::W_RING + slot * Cfg::W_BYTES + lw * Cfg::W_COPIES * 1024;
 #pragma unroll
     for (int j = 0; j < Cfg::W_COPIES; ++j)
-#ifdef STRIPE_TEST_LINEAR
-      lds_dma16_nt(w_src[j] + (int64_t)stage * 16 * Cfg::BN, sb + j * 1024);
-#else
-      lds_dma16_nt(w_src[j] + (int64_t)stage * 16 * n, sb + j * 1024);
-#endif
+      lds_dma16_s_nt(qw + (int64_t)stage * 16 * n, w_off[j], sb + j * 1024);
   };
   auto issue_a = [&](int slot, int stage) {
 #if defined(STRIPE_ABLATE_DMA) || defined(STRIPE_NO_A)
@@ -193,7 +186,7 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
     const uint32_t sb = lds_base + Cfg::A_RING + slot * Cfg::A_BYTES;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
-      lds_dma16(a_src[i] + stage * kStBK, sb + (i * 4 + lw) * 1024);
+      lds_dma16_s(a + stage * kStBK, a_off[i], sb + (i * 4 + lw) * 1024);
     const int g = (stage * kStBK + my_set * (kStBK / SETS)) / group;
     if (sc_lane) lds_dma16(sc_src + (int64_t)g * sc_gstride, sb + Cfg::A_IMG_BYTES + my_set * Cfg::SET_BYTES);
   };
