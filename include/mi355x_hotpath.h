@@ -263,6 +263,16 @@ int mi355x_awq_gemm_deferred(void* c, const void* a, const uint32_t* qweight, co
                              int group_size, int64_t lda, int dtype, int* sk_out,
                              mi355x_stream stream);
 
+/* MI355X-side prefill fusion: out[M, N/2] = silu_and_mul(awq_gemm(a, W_gate_up)) in one GEMM launch
+ * (the epilogue applies csrc/activation_kernels.cu:14-36 to the T-rounded accumulators: bit-identical
+ * to awq_gemm followed by silu_and_mul, without writing and re-reading the [M, N] intermediate).
+ * Prefill-sized only: m >= 1024, n % 256 == 0, dq_workspace >= (n + roundup(m,16))*k*2 bytes;
+ * otherwise MI355X_EUNSUPPORTED (call the two ops). */
+int mi355x_awq_gemm_silu_mul(void* out, const void* a, const uint32_t* qweight, const void* scales,
+                             const uint32_t* qzeros, void* dq_workspace, int64_t dq_workspace_bytes,
+                             int m, int n, int k, int group_size, int64_t lda, int dtype,
+                             mi355x_stream stream);
+
 /* gptq_shuffle: in-place exllama nibble shuffle of q_weight [K/8, N]; with q_perm
  * (int32 [K]) rows are first made sequential through `scratch` (>= K/8*N words).
  * ref: csrc/quantization/gptq/q_gemm.cu:2415-2423, :2321-2368, qdq_4.cuh:16-29,

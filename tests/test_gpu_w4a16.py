@@ -235,3 +235,22 @@ def test_deferred_split_k_plus_norm_is_bit_identical(m, k, n):
         assert_bit_exact(res, ref_res, "deferred norm residual")
     if (m, k, n) == (64, 4096, 4096):
         assert saw_slabs          # the Llama-3-8B o_proj shape does split K
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,n", [(1024, 512, 512), (1300, 256, 1280)])
+def test_gate_up_gemm_with_fused_silu_is_bit_identical(dtype, m, k, n):
+    """MI355X-side prefill fusion: awq_gemm_silu_mul == silu_and_mul(awq_gemm) bit for bit
+    (n = 2 * ffn; ragged M, several 128-column blocks, both dtypes)."""
+    qw, qz, sc, _, _ = make_awq(k, n, 128, dtype, seed=31)
+    d = dev()
+    q2d = ops().awq_to_gptq_4bit(qw.to(d))
+    qz, sc = qz.to(d), sc.to(d)
+    x = (torch.randn(m, k, generator=torch.Generator().manual_seed(32)) * 0.5).to(dtype).to(d)
+    gu = ops().awq_gemm(x, q2d, qz, sc, 8, torch.empty(0), dtype == torch.bfloat16)
+    ref = torch.empty(m, n // 2, dtype=dtype, device=d)
+    ops().silu_and_mul(ref, gu)
+    out = ops().awq_gemm_silu_mul(x, q2d, qz, sc)
+    assert out is not None
+    assert_bit_exact(out, ref, "fused silu epilogue")
+    assert ops().awq_gemm_silu_mul(x[:64], q2d, qz, sc) is None      # decode-sized: not applicable

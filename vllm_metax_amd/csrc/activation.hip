@@ -8,12 +8,6 @@
 
 namespace mi355x {
 
-template <typename T>
-__device__ __forceinline__ T silu_t(T x) {
-  const float xf = to_f32(x);
-  return from_f32<T>(xf / (1.0f + expf(-xf)));
-}
-
 template <typename T, bool VEC>
 __global__ void silu_and_mul_kernel(T* __restrict__ out, const T* __restrict__ in, int d) {
   const int64_t token = blockIdx.y;

@@ -131,6 +131,13 @@ __device__ __forceinline__ void store16(T* p, const Vec16<T>& v) {
   *reinterpret_cast<uint4*>(p) = v.u;
 }
 
+// SiLU in the reference's arithmetic (csrc/activation_kernels.cu:142-147): fp32, rounded to T
+template <typename T>
+__device__ __forceinline__ T silu_t(T x) {
+  const float xf = to_f32(x);
+  return from_f32<T>(xf / (1.0f + expf(-xf)));
+}
+
 // rotary pair in scalar_t arithmetic (ref: csrc/pos_encoding_kernels.cu:10-34): a rounding after
 // every multiply and after the add / sub, like the c10 scalar operators.
 template <typename T>

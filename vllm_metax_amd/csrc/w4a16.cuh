@@ -171,6 +171,7 @@ struct GemmArgs {
   int zmode;
   hipStream_t stream;
   int* defer_sk = nullptr;   // non-null: leave split-K slabs unreduced, report their count here
+  bool fuse_silu = false;    // prefill gate_up: write silu_and_mul(C) [m, n/2] instead of C
 };
 
 

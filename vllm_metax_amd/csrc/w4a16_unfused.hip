@@ -70,7 +70,11 @@ constexpr int kUfBK = 32;
 constexpr int kUfStages = 4;
 constexpr int kUfThreads = 512;
 
-template <typename T>
+// SILU = true: the GEMM is a gate_up projection (n = 2 * ffn, gate columns first) and the epilogue
+// writes act[M, ffn] = silu_and_mul(C) instead of C (csrc/activation_kernels.cu:14-36): a tile is
+// then 128 gate columns + the 128 matching up columns, and every wave owns 2 gate column tiles
+// and the 2 matching up column tiles, so gate and up of one output element sit in ONE lane.
+template <typename T, bool SILU>
 __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     T* __restrict__ c, const uint4* __restrict__ pa, const uint4* __restrict__ pb, int m, int n,
     int k, int num_m_blocks, int num_tiles) {
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     gmt = gmt < max_mt ? gmt : max_mt;
     a_src[i] = pa + (int64_t)gmt * kt32 * 64 + lane;
     int gnt = nb * 16 + p;
+    if constexpr (SILU) gnt = p < 8 ? nb * 8 + p : (n >> 5) + nb * 8 + (p - 8);   // gate | up tiles
     const int max_nt = (n >> 4) - 1;
     gnt = gnt < max_nt ? gnt : max_nt;
     b_src[i] = pb + (int64_t)gnt * kt32 * 64 + lane;
@@ -167,12 +172,13 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
       if (nxt < ktiles) stage(slot, nxt);
     }
     const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
-    const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
+    // SILU: pieces 2wn, 2wn+1 (gate) and 8+2wn, 8+2wn+1 (up); else pieces 4wn .. 4wn+3
+    const uint4* bbuf = lds + cur * kStage + kBOff + (SILU ? wn * 2 : wn * 4) * 64 + frag;
     // all 12 fragment reads of the stage go out before the first MFMA (the scheduler would
     // otherwise pair each A read with its 4 MFMAs and expose the LDS latency 8 times per stage)
     uint4 bf[4], af[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bf[t] = bbuf[t * 64];
+    for (int t = 0; t < 4; ++t) bf[t] = bbuf[(SILU ? (t < 2 ? t : 6 + t) : t) * 64];
 #pragma unroll
     for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
     __builtin_amdgcn_sched_barrier(0);
@@ -185,6 +191,27 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   }
 
   // ---- epilogue: lane holds 4 consecutive columns per (i, j) --------------------------------
+  if constexpr (SILU) {
+    // tiles t = 0,1: gate columns col, col+1; t = 2,3: the same columns of the up half
+    const int half = n >> 1;
+    const int col = nb * 128 + 64 * (wn >> 1) + 4 * lc + 2 * (wn & 1);
+    if (col >= half) return;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = mb * kUfBM + wm * 128 + i * 16 + 4 * lr + j;
+        if (row < m) {
+          // exactly gemm -> T, then silu_and_mul on the T values
+          const T g0 = from_f32<T>(acc[i][0][j]), g1 = from_f32<T>(acc[i][1][j]);
+          const T u0 = from_f32<T>(acc[i][2][j]), u1 = from_f32<T>(acc[i][3][j]);
+          T o[2] = {mul_t<T>(silu_t<T>(g0), u0), mul_t<T>(silu_t<T>(g1), u1)};
+          *reinterpret_cast<uint32_t*>(c + (int64_t)row * half + col) = *reinterpret_cast<const uint32_t*>(o);
+        }
+      }
+    }
+    return;
+  }
   const int ncol = nb * kUfBN + wn * 64 + 4 * lc;
   if (ncol >= n) return;
 #pragma unroll
@@ -206,7 +233,7 @@ static inline int64_t unfused_scratch_bytes(int m, int n, int k) {
   return ((int64_t)n + m_pad) * k * 2;
 }
 
-template <typename T>
+template <typename T, bool SILU>
 static int run_unfused(const GemmArgs& g) {
   T* packed_b = static_cast<T*>(g.dq_ws);
   T* packed_a = packed_b + (int64_t)g.n * g.k;
@@ -228,11 +255,12 @@ static int run_unfused(const GemmArgs& g) {
   rc = check_launch("pack_a");
   if (rc) return rc;
   const int num_m_blocks = (g.m + kUfBM - 1) / kUfBM;
-  const int num_n_blocks = (g.n + kUfBN - 1) / kUfBN;
+  // SILU: a tile = 128 gate + 128 up columns, i.e. one block per 128 output columns
+  const int num_n_blocks = SILU ? (g.n / 2 + 127) / 128 : (g.n + kUfBN - 1) / kUfBN;
   const int num_tiles = num_m_blocks * num_n_blocks;
   const size_t smem = (size_t)kUfStages * 2048 * sizeof(uint4);  // 128 KiB
-  auto kern = gemm_packed_kernel<T>;
-  static bool attr_set = false;  // one flag per instantiation (T)
+  auto kern = gemm_packed_kernel<T, SILU>;
+  static bool attr_set = false;  // one flag per instantiation (T, SILU)
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -254,8 +282,14 @@ int w4a16_gemm_unfused_dispatch(const GemmArgs& g, int dtype) {
   if (g.dq_ws_bytes < unfused_scratch_bytes(g.m, g.n, g.k)) return 1;
   if (g.k % kUfBK != 0 || g.n % 64 != 0) return 1;
   if (g.m < 1024) return 1;   // too few 256-row tiles to fill 256 CUs below that
-  if (dtype == MI355X_BF16) return run_unfused<bf16_t>(g);
-  if (dtype == MI355X_F16) return run_unfused<f16_t>(g);
+  if (g.fuse_silu) {
+    if (g.n % 256 != 0) return 1;   // gate and up halves must each be whole 128-column blocks
+    if (dtype == MI355X_BF16) return run_unfused<bf16_t, true>(g);
+    if (dtype == MI355X_F16) return run_unfused<f16_t, true>(g);
+    return 1;
+  }
+  if (dtype == MI355X_BF16) return run_unfused<bf16_t, false>(g);
+  if (dtype == MI355X_F16) return run_unfused<f16_t, false>(g);
   return 1;
 }
 

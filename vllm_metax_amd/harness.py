@@ -123,6 +123,12 @@ class QLinear:
             return out
         return torch.matmul(x, self.weight)
 
+    def silu_mul(self, x: torch.Tensor):
+        """silu_and_mul(self(x)) in one launch where the library supports it (AWQ, M >= 1024), else None."""
+        if self.quant == "awq":
+            return ops.awq_gemm_silu_mul(x, self.qweight, self.qzeros, self.scales)
+        return None
+
     def deferred(self, x: torch.Tensor):
         """(out, slabs, sk): like __call__, but a decode-sized AWQ GEMM may leave its split-K
         slabs unreduced for ops.fused_add_rms_norm_slabs (sk == 0: `out` is final)."""
@@ -242,9 +248,11 @@ class HotPathModel:
         else:
             o = self._all_reduce(L.o(attn.view(-1, L.q_size)))
             ops.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
-        gu = L.gate_up(o)
-        act = torch.empty(gu.shape[0], L.ffn, dtype=gu.dtype, device=gu.device)
-        ops.silu_and_mul(act, gu)
+        act = L.gate_up.silu_mul(o)            # prefill-sized AWQ: fused into the GEMM epilogue
+        if act is None:
+            gu = L.gate_up(o)
+            act = torch.empty(gu.shape[0], L.ffn, dtype=gu.dtype, device=gu.device)
+            ops.silu_and_mul(act, gu)
         if fuse:
             out, slabs, sk = L.down.deferred(act)
             return out, residual, (slabs, sk)
