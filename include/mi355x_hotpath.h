@@ -266,7 +266,8 @@ int mi355x_awq_gemm_deferred(void* c, const void* a, const uint32_t* qweight, co
 /* MI355X-side prefill fusion: out[M, N/2] = silu_and_mul(awq_gemm(a, W_gate_up)) in one GEMM launch
  * (the epilogue applies csrc/activation_kernels.cu:14-36 to the T-rounded accumulators: bit-identical
  * to awq_gemm followed by silu_and_mul, without writing and re-reading the [M, N] intermediate).
- * Prefill-sized only: m >= 1024, n % 256 == 0, dq_workspace >= (n + roundup(m,16))*k*2 bytes;
+ * m <= 64 (decode: n % 128 == 0, k % 128 == 0, group 32/64/128k; dq_workspace unused) or
+ * m >= 1024 (prefill: n % 256 == 0, dq_workspace >= (n + roundup(m,16))*k*2 bytes);
  * otherwise MI355X_EUNSUPPORTED (call the two ops). */
 int mi355x_awq_gemm_silu_mul(void* out, const void* a, const uint32_t* qweight, const void* scales,
                              const uint32_t* qzeros, void* dq_workspace, int64_t dq_workspace_bytes,

@@ -238,7 +238,8 @@ def test_deferred_split_k_plus_norm_is_bit_identical(m, k, n):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("m,k,n", [(1024, 512, 512), (1300, 256, 1280)])
+@pytest.mark.parametrize("m,k,n", [(1024, 512, 512), (1300, 256, 1280), (64, 4096, 28672), (7, 256, 384),
+                                   (33, 512, 128)])
 def test_gate_up_gemm_with_fused_silu_is_bit_identical(dtype, m, k, n):
     """MI355X-side prefill fusion: awq_gemm_silu_mul == silu_and_mul(awq_gemm) bit for bit
     (n = 2 * ffn; ragged M, several 128-column blocks, both dtypes)."""
@@ -253,4 +254,4 @@ def test_gate_up_gemm_with_fused_silu_is_bit_identical(dtype, m, k, n):
     out = ops().awq_gemm_silu_mul(x, q2d, qz, sc)
     assert out is not None
     assert_bit_exact(out, ref, "fused silu epilogue")
-    assert ops().awq_gemm_silu_mul(x[:64], q2d, qz, sc) is None      # decode-sized: not applicable
+    assert ops().awq_gemm_silu_mul(x[:1].expand(300, k).contiguous(), q2d, qz, sc) is None   # 64 < M < 1024

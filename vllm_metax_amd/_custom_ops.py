@@ -552,23 +552,31 @@ def qkv_rope_cache(qkv: torch.Tensor, slabs: Optional[torch.Tensor], sk: int,
 def awq_gemm_silu_mul(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
                       scales: torch.Tensor) -> Optional[torch.Tensor]:
     """MI355X-side prefill fusion: silu_and_mul(awq_gemm(input, W_gate_up)) -> [M, N/2] in one GEMM
-    launch, bit-identical to the two ops.  Returns None when the fused path does not apply
-    (M < 1024, N % 256 != 0, ...): the caller then runs awq_gemm + silu_and_mul."""
+    launch, bit-identical to the two ops (decode M <= 64: stripe kernel; prefill M >= 1024: packed
+    GEMM).  Returns None when the fused path does not apply (64 < M < 1024, odd shapes): the caller
+    then runs awq_gemm + silu_and_mul."""
     _dev(input, qweight, qzeros, scales)
     if input.dim() != 2 or input.stride(1) != 1:
         raise RuntimeError("awq_gemm_silu_mul: input must be [M, K] with unit inner stride")
     m, k = input.shape
     n = qweight.size(0)
-    if m < 1024 or n % 256 != 0 or k % 32 != 0 or input.dtype not in (torch.bfloat16, torch.float16):
+    if input.dtype not in (torch.bfloat16, torch.float16):
         return None
     group = k // scales.size(0)
-    dq = _dq_scratch(m, n, k, input.device)
-    if dq is None:
-        return None
+    if m <= 64:                       # decode: stripe kernel with the silu epilogue
+        if n % 128 != 0 or k % 128 != 0 or not (group % 128 == 0 or group in (32, 64)):
+            return None
+        dq = None
+    else:                             # prefill: packed GEMM with the silu epilogue
+        if m < 1024 or n % 256 != 0 or k % 32 != 0:
+            return None
+        dq = _dq_scratch(m, n, k, input.device)
+        if dq is None:
+            return None
     out = torch.empty((m, n // 2), dtype=input.dtype, device=input.device)
     rc = _abi.load().mi355x_awq_gemm_silu_mul(
-        _ptr(out), _ptr(input), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(dq), dq.numel(),
-        m, n, k, group, input.stride(0), _dt(input), _stream())
+        _ptr(out), _ptr(input), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(dq),
+        dq.numel() if dq is not None else 0, m, n, k, group, input.stride(0), _dt(input), _stream())
     _abi.check(rc, "awq_gemm_silu_mul")
     return out
 

@@ -331,6 +331,7 @@ __global__ __launch_bounds__(kSmThreads, 4) void w4a16_gemm_small_m_kernel(
 int w4a16_gemm_large_m_dispatch(const GemmArgs& g, int dtype);  // w4a16_large.hip
 int w4a16_gemm_unfused_dispatch(const GemmArgs& g, int dtype);  // w4a16_unfused.hip
 int w4a16_gemm_stripe_dispatch(const GemmArgs& g, int dtype, int row0, int rows);  // w4a16_stripe.hip
+int w4a16_gemm_stripe_silu_dispatch(const GemmArgs& g, int dtype);                  // w4a16_stripe.hip
 
 template <typename T, int ZMODE>
 static int launch_small_m(const GemmArgs& g, int row0, int rows) {
@@ -541,11 +542,11 @@ int mi355x_awq_gemm_silu_mul(void* out, const void* a, const uint32_t* qweight, 
   g.fuse_silu = true;
   int rc = validate_gemm(g, "awq_gemm_silu_mul");
   if (rc || m == 0) return rc;
-  rc = w4a16_gemm_unfused_dispatch(g, dtype);
+  rc = m <= 64 ? w4a16_gemm_stripe_silu_dispatch(g, dtype) : w4a16_gemm_unfused_dispatch(g, dtype);
   MI355X_REQUIRE(rc != 1, MI355X_EUNSUPPORTED,
-                 "awq_gemm_silu_mul: needs m >= 1024, n %% 256 == 0, k %% 32 == 0, a 2-byte dtype and "
-                 "dq_workspace >= (n + roundup(m,16))*k*2 bytes (got m=%d n=%d k=%d, %lld bytes); use "
-                 "awq_gemm + silu_and_mul",
+                 "awq_gemm_silu_mul: needs a 2-byte dtype and either m <= 64 (n %% 128 == 0, k %% 128 == 0, "
+                 "group 32/64/128k) or m >= 1024 (n %% 256 == 0, k %% 32 == 0, dq_workspace >= "
+                 "(n + roundup(m,16))*k*2 bytes); got m=%d n=%d k=%d, %lld bytes; use awq_gemm + silu_and_mul",
                  m, n, k, (long long)dq_workspace_bytes);
   return rc;
 }

@@ -83,7 +83,11 @@ __device__ __forceinline__ void lds_dma16_nt(const void* gptr, uint32_t lds_base
                : "memory");
 }
 
-template <typename T, int MT, int NW, int ZMODE, int SETS>
+// SILU = true (NW == 2, no K split): the GEMM is a gate_up projection (n = 2 * ffn, gate columns
+// first); a stripe is then 64 gate columns (column wave 0) + the 64 matching up columns (column
+// wave 1) and the epilogue writes act[M, ffn] = silu_and_mul(C) (csrc/activation_kernels.cu:14-36
+// applied to the T-rounded accumulators: the bits of awq_gemm followed by silu_and_mul).
+template <typename T, int MT, int NW, int ZMODE, int SETS, bool SILU = false>
 __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIMD)) void w4a16_gemm_stripe_kernel(
     T* __restrict__ c, float* __restrict__ slabs, const T* __restrict__ a, int64_t lda,
     const uint32_t* __restrict__ qw, const T* __restrict__ scales, const uint32_t* __restrict__ qz,
@@ -98,7 +102,11 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
   const int lc = lane & 15;
   const int lr = lane >> 4;
   const int n0 = blockIdx.x * Cfg::BN;
-  const int kt32 = k >> 5;
+  // stripe-local column (multiple of 4) -> global column
+  auto gcol = [&](int local) {
+    if constexpr (SILU) return (local < 64 ? 0 : (n >> 1) - 64) + (int)blockIdx.x * 64 + local;
+    else return n0 + local;
+  };
   const int total_stages = k / kStBK;
   const int s_begin = blockIdx.y * stages_per_split;
   const int s_end = min(s_begin + stages_per_split, total_stages);
@@ -108,7 +116,13 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
   // apart and so live in ONE L2 channel (256-B interleave, pitch a multiple of 4 KiB): in
   // lock-step the 28-32 workgroups of an XCD would all queue on that channel.  Workgroups b, b+8,
   // b+16.. share an XCD (round-robin dispatch), so consecutive b/8 get consecutive start stages.
-  const int rot = nst > 0 ? (int)(((blockIdx.x >> 3) + 4u * (blockIdx.x & 7) + 7u * blockIdx.y) % (unsigned)nst) : 0;
+  // (the start stage is a function of the 128-column block index modulo HALF the block count, so
+  //  that the gate and the up half of a gate_up projection — and the SILU variant, whose stripes
+  //  are 64 + 64 columns — accumulate every column in the same order: bit-identical outputs)
+  const unsigned bq = SILU ? (blockIdx.x >> 1) : blockIdx.x;
+  const unsigned period = SILU ? (unsigned)(n >> 8) : ((gridDim.x + 1) >> 1);
+  const unsigned br = bq % (period ? period : 1u);
+  const int rot = nst > 0 ? (int)(((br >> 3) + 4u * (br & 7) + 7u * blockIdx.y) % (unsigned)nst) : 0;
   auto stage_of = [&](int i) {
     int s = i + rot;
     s = s >= nst ? s - nst : s;
@@ -129,7 +143,7 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
     for (int j = 0; j < Cfg::W_COPIES; ++j) {
       const int p = lw * Cfg::W_COPIES + j;
       const int r = p * RPP + lane / LPR;
-      int col = n0 + 4 * (lane % LPR);
+      int col = gcol(4 * (lane % LPR));
       col = col <= n - 4 ? col : n - 4;
       w_off[j] = (uint32_t)(((int64_t)r * n + col) * 4);
     }
@@ -159,12 +173,12 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
   const char* sc_src;       // + g * sc_gstride per group
   int64_t sc_gstride;
   if (lane < Cfg::SC_LANES) {
-    int col = n0 + 8 * lane;
+    int col = gcol(8 * lane);
     col = col <= n - 8 ? col : n - 8;
     sc_src = reinterpret_cast<const char*>(scales + col);
     sc_gstride = (int64_t)n * sizeof(T);
   } else {
-    int zw = (n0 >> 3) + 4 * (lane - Cfg::SC_LANES);
+    int zw = gcol(32 * (lane - Cfg::SC_LANES)) >> 3;
     zw = zw <= (n >> 3) - 4 ? zw : (n >> 3) - 4;
     sc_src = reinterpret_cast<const char*>(qz + zw);
     sc_gstride = (int64_t)(n >> 3) * 4;
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
   // byte offset of this lane's A fragment inside a row tile, without the k-step term (see above)
   const int a_rd = (lc >> 2) * 1024 + (lc & 3) * 256 + ((lr ^ (lc & 3)) << 4);
   const int colw = 64 * wn + 4 * lc;       // first of this lane's 4 columns inside the stripe
-  const int ncol = n0 + colw;
+  const int ncol = gcol(colw);
   int cur_w = 0, cur_a = 0;                // ring slots of stage `it`
   for (int it = 0; it < nst; ++it) {
     // stage `it` has landed once only the copies of the stages issued after it are pending
@@ -318,23 +332,60 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
     }
   }
   __syncthreads();
-  if (wk > 0 || ncol >= n) return;
+  if (wk == 0) {
 #pragma unroll 1
-  for (int w = 1; w < Cfg::KW; ++w) {
-    const float* src = red + ((w - 1) * NW + wn) * kSlab;
+    for (int w = 1; w < Cfg::KW; ++w) {
+      const float* src = red + ((w - 1) * NW + wn) * kSlab;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = i * 16 + 4 * lr + j;
+          const float4 v = *reinterpret_cast<const float4*>(src + row * 64 + 4 * lc);
+          acc[i][0][j] += v.x;
+          acc[i][1][j] += v.y;
+          acc[i][2][j] += v.z;
+          acc[i][3][j] += v.w;
+        }
+      }
+    }
+  }
+  if constexpr (SILU) {
+    // column wave 1 (up) hands its tile to column wave 0 (gate) through LDS: same lane layout
+    __syncthreads();                 // all partial sums have been read
+    if (wk == 0 && wn == 1) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = i * 16 + 4 * lr + j;
+          *reinterpret_cast<float4*>(red + row * 64 + 4 * lc) =
+              make_float4(acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]);
+        }
+      }
+    }
+    __syncthreads();
+    if (wk != 0 || wn != 0) return;
+    const int half = n >> 1;
+    const int ocol = (int)blockIdx.x * 64 + 4 * lc;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = i * 16 + 4 * lr + j;
-        const float4 v = *reinterpret_cast<const float4*>(src + row * 64 + 4 * lc);
-        acc[i][0][j] += v.x;
-        acc[i][1][j] += v.y;
-        acc[i][2][j] += v.z;
-        acc[i][3][j] += v.w;
+        if (row >= m) continue;
+        const float4 u = *reinterpret_cast<const float4*>(red + row * 64 + 4 * lc);
+        const float uu[4] = {u.x, u.y, u.z, u.w};
+        T o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          o[t] = mul_t<T>(silu_t<T>(from_f32<T>(acc[i][t][j])), from_f32<T>(uu[t]));
+        *reinterpret_cast<uint2*>(c + (int64_t)row * half + ocol) = *reinterpret_cast<const uint2*>(o);
       }
     }
+    return;
   }
+  if (wk > 0 || ncol >= n) return;
   float* slab = slabs + (int64_t)blockIdx.y * m * n;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -403,10 +454,10 @@ static StripePlan plan_stripe(int rows, int n, int k, int64_t ws_elems) {
   return best;
 }
 
-template <typename T, int MT, int NW, int ZMODE, int SETS>
+template <typename T, int MT, int NW, int ZMODE, int SETS, bool SILU = false>
 static int launch_stripe_cfg(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p) {
   using Cfg = StripeCfg<MT, NW, SETS>;
-  auto kern = w4a16_gemm_stripe_kernel<T, MT, NW, ZMODE, SETS>;
+  auto kern = w4a16_gemm_stripe_kernel<T, MT, NW, ZMODE, SETS, SILU>;
   static bool attr_set = false;  // one per instantiation
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -418,7 +469,7 @@ static int launch_stripe_cfg(const GemmArgs& g, const T* a, T* c, int rows, cons
     }
     attr_set = true;
   }
-  const int stripes = (g.n + Cfg::BN - 1) / Cfg::BN;
+  const int stripes = SILU ? g.n / 128 : (g.n + Cfg::BN - 1) / Cfg::BN;
   hipLaunchKernelGGL(kern, dim3(stripes, p.sk), dim3(kStThreads), Cfg::LDS_BYTES, g.stream, c, g.ws,
                      a, g.lda, g.qw, static_cast<const T*>(g.scales), g.qz,
                      rows, g.n, g.k, g.group, p.steps);
@@ -473,6 +524,39 @@ static int run_stripe(const GemmArgs& g, int row0, int rows) {
     rc = check_launch("w4a16_sum_slabs");
   }
   return rc;
+}
+
+// gate_up + silu_and_mul in one launch (decode): AWQ zero points, no K split, 64+64 columns per
+// stripe.  Returns 1 when not applicable.
+template <typename T>
+static int run_stripe_silu(const GemmArgs& g) {
+  if (g.m > 64 || g.m < 1 || g.k % kStBK != 0 || g.n % 128 != 0 || g.zmode != kZeroAwq) return 1;
+  int sets;
+  if (g.group % 128 == 0) sets = 1;
+  else if (g.group == 64) sets = 2;
+  else if (g.group == 32) sets = 4;
+  else return 1;
+  if ((reinterpret_cast<uintptr_t>(g.qw) & 15) || (reinterpret_cast<uintptr_t>(g.scales) & 15) ||
+      (reinterpret_cast<uintptr_t>(g.qz) & 15) || (reinterpret_cast<uintptr_t>(g.c) & 7))
+    return 1;
+  const T* a = static_cast<const T*>(g.a);
+  T* c = static_cast<T*>(g.c);
+  const StripePlan p{2, 1, g.k / kStBK, 0.0};
+  const int mt = (g.m + 15) / 16;
+#define STRIPE_S(MTV)                                                                         \
+  (sets == 1 ? launch_stripe_cfg<T, MTV, 2, kZeroAwq, 1, true>(g, a, c, g.m, p)               \
+             : (sets == 2 ? launch_stripe_cfg<T, MTV, 2, kZeroAwq, 2, true>(g, a, c, g.m, p)  \
+                          : launch_stripe_cfg<T, MTV, 2, kZeroAwq, 4, true>(g, a, c, g.m, p)))
+  if (mt <= 1) return STRIPE_S(1);
+  if (mt <= 2) return STRIPE_S(2);
+  return STRIPE_S(4);
+#undef STRIPE_S
+}
+
+int w4a16_gemm_stripe_silu_dispatch(const GemmArgs& g, int dtype) {
+  if (dtype == MI355X_BF16) return run_stripe_silu<bf16_t>(g);
+  if (dtype == MI355X_F16) return run_stripe_silu<f16_t>(g);
+  return 1;
 }
 
 int w4a16_gemm_stripe_dispatch(const GemmArgs& g, int dtype, int row0, int rows) {
