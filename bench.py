@@ -261,11 +261,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    # rehearsal on a 1-GPU box: BENCH_DIST_BACKEND=gloo BENCH_SHARE_GPU0=1 runs N ranks on cuda:0
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_GPU0") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            torch.distributed.init_process_group(backend)
         group = torch.distributed.group.WORLD
 
     from vllm_metax_amd import harness
