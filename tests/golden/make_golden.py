@@ -32,7 +32,12 @@ def raw(t: torch.Tensor) -> np.ndarray:
     return t.numpy()
 
 
+ONLY = set(sys.argv[1:])   # optional: regenerate just the named fixtures
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     np.savez_compressed(OUT / f"{name}.npz", **{k: (raw(v) if isinstance(v, torch.Tensor) else v)
                                                 for k, v in arrays.items()})
     print(f"{name}.npz", {k: tuple(np.shape(v)) for k, v in arrays.items()})
@@ -147,6 +152,17 @@ def main():
     b_s = torch.rand(1, 64, generator=g) * 9e-3 + 1e-3
     save("scaled_mm_fp8", a=a, b_nk=b, a_scales=a_s.numpy(), b_scales=b_s.numpy(),
          out=R.scaled_mm_fp8(a, b.t(), a_s, b_s, bf))
+
+    # ---- merge_attn_states ------------------------------------------------------
+    g = torch.Generator().manual_seed(8)
+    n, h, d = 13, 4, 64
+    p_out, s_out = torch.randn(n, h, d, generator=g).to(bf), torch.randn(n, h, d, generator=g).to(bf)
+    p_lse, s_lse = torch.randn(h, n, generator=g) * 3, torch.randn(h, n, generator=g) * 3
+    p_lse[0, 1] = float("inf")
+    s_lse[2, 7] = float("inf")
+    m_out, m_lse = R.merge_attn_states(p_out, p_lse, s_out, s_lse)
+    save("merge_attn_states", prefix_output=p_out, prefix_lse=p_lse.numpy(), suffix_output=s_out,
+         suffix_lse=s_lse.numpy(), output=m_out, output_lse=m_lse.numpy())
 
 
 if __name__ == "__main__":

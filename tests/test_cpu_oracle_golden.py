@@ -191,3 +191,12 @@ def test_merge_attn_states_oracle_matches_the_in_test_formula():
     assert torch.allclose(lse, torch.log(pe + se) + m, rtol=1e-6, atol=1e-7)
     # a +inf lse removes that side entirely
     assert torch.equal(out[:5, 0], s_out[:5, 0]) and torch.equal(out[5:9, 1], p_out[5:9, 1])
+
+
+def test_golden_merge_attn_states():
+    """The frozen fixture pins the oracle (tests/golden/make_golden.py merge_attn_states)."""
+    z = G.load("merge_attn_states")
+    out, lse = R.merge_attn_states(G.bf16(z["prefix_output"]), G.f32(z["prefix_lse"]),
+                                   G.bf16(z["suffix_output"]), G.f32(z["suffix_lse"]))
+    assert torch.equal(out.view(torch.int16), G.bf16(z["output"]).view(torch.int16))
+    assert torch.equal(lse, G.f32(z["output_lse"]))

@@ -68,3 +68,15 @@ def test_merge_attn_states_checks():
     # empty batch is a no-op
     e = torch.empty(0, 2, 64, dtype=torch.bfloat16, device=dv)
     ops().merge_attn_states(e, e.clone(), torch.zeros(2, 0, device=dv), e.clone(), torch.zeros(2, 0, device=dv))
+
+
+def test_golden_merge_attn_states_gpu():
+    from tests import golden_io as G
+    z = G.load("merge_attn_states")
+    dv = dev()
+    po, so = G.bf16(z["prefix_output"]).to(dv), G.bf16(z["suffix_output"]).to(dv)
+    out = torch.empty_like(po)
+    lse = torch.empty(po.shape[1], po.shape[0], device=dv)
+    ops().merge_attn_states(out, po, G.f32(z["prefix_lse"]).to(dv), so, G.f32(z["suffix_lse"]).to(dv), lse)
+    assert_mostly_exact(out, G.bf16(z["output"]), 1, 0.01, "golden output")
+    assert_close_rel(lse, G.f32(z["output_lse"]), 2e-6, "golden lse")
