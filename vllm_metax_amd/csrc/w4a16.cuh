@@ -112,28 +112,37 @@ __device__ __forceinline__ int frag_swz(int lr, int lc) {
 // ---- pack activations into operand images ------------------------------------------------
 // A [M, K] row-major -> pieces PA[mt][kt][64 slots x 16 B] in the same swizzled operand image
 // (slot swz(lr, lc) = A[16 mt + lc][32 kt + 8 lr .. +7]); rows >= M are zero.  One workgroup
-// packs 16 rows x 256 k: coalesced 16-B reads (a row's 512 contiguous bytes by 32 lanes), the
-// shuffle happens in LDS, the 8 KiB image is written out linearly.
+// packs 16 rows x kPackK k: coalesced 16-B reads (a row's 2 KiB by 128 lanes), all 8 loads of a
+// thread in flight before the shuffle in LDS, the 32 KiB image is written out linearly.
+constexpr int kPackK = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_a_kernel(T* __restrict__ packed, const T* __restrict__ a,
                                                      int m, int k, int64_t lda) {
-  __shared__ uint4 img[8 * 64];
+  __shared__ uint4 img[(kPackK / 32) * 64];        // 32 pieces of 1 KiB
   const int mt = blockIdx.y;
-  const int k0 = blockIdx.x * 256;                 // first k of this block (8 pieces of 32)
+  const int k0 = blockIdx.x * kPackK;              // first k of this block
   const int kt32 = k >> 5;
+  constexpr int kChunksPerRow = kPackK / 8;        // 16-B chunks per row
+  constexpr int kIters = 16 * kChunksPerRow / 256; // 8
+  uint4 v[kIters];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = threadIdx.x + i * 256;         // 0..511 : row = idx / 32, chunk = idx % 32
-    const int r = idx >> 5, ch = idx & 31;
+  for (int i = 0; i < kIters; ++i) {
+    const int idx = threadIdx.x + i * 256;         // row = idx / 128, chunk = idx % 128
+    const int r = idx / kChunksPerRow, ch = idx % kChunksPerRow;
     const int row = mt * 16 + r;
     const int kk = k0 + ch * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < m && kk < k) v = *reinterpret_cast<const uint4*>(a + (int64_t)row * lda + kk);
-    img[(ch >> 2) * 64 + frag_swz(ch & 3, r)] = v;
+    v[i] = make_uint4(0, 0, 0, 0);
+    if (row < m && kk < k) v[i] = *reinterpret_cast<const uint4*>(a + (int64_t)row * lda + kk);
+  }
+#pragma unroll
+  for (int i = 0; i < kIters; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    const int r = idx / kChunksPerRow, ch = idx % kChunksPerRow;
+    img[(ch >> 2) * 64 + frag_swz(ch & 3, r)] = v[i];
   }
   __syncthreads();
   uint4* dst = reinterpret_cast<uint4*>(packed) + ((int64_t)mt * kt32 + (k0 >> 5)) * 64;
-  const int pieces = min(8, kt32 - (k0 >> 5));
+  const int pieces = min(kPackK / 32, kt32 - (k0 >> 5));
   for (int idx = threadIdx.x; idx < pieces * 64; idx += 256) dst[idx] = img[idx];
 }
 

@@ -360,7 +360,7 @@ static int launch_small_m(const GemmArgs& g, int row0, int rows) {
   const uint4* a_packed = nullptr;
   const int64_t pack_bytes = (int64_t)mt * 16 * g.k * 2;
   if (g.dq_ws != nullptr && g.dq_ws_bytes >= pack_bytes && g.k % 32 == 0) {
-    hipLaunchKernelGGL(pack_a_kernel<T>, dim3((g.k + 255) / 256, mt), dim3(256), 0, g.stream,
+    hipLaunchKernelGGL(pack_a_kernel<T>, dim3((g.k + kPackK - 1) / kPackK, mt), dim3(256), 0, g.stream,
                        static_cast<T*>(g.dq_ws), a, rows, g.k, g.lda);
     int prc = check_launch("pack_a(small)");
     if (prc) return prc;

@@ -250,7 +250,7 @@ static int run_unfused(const GemmArgs& g) {
   int rc = check_launch("w4_dequant_pack");
   if (rc) return rc;
   const int m_tiles = (g.m + 15) / 16;
-  hipLaunchKernelGGL(pack_a_kernel<T>, dim3((g.k + 255) / 256, m_tiles), dim3(256), 0, g.stream,
+  hipLaunchKernelGGL(pack_a_kernel<T>, dim3((g.k + kPackK - 1) / kPackK, m_tiles), dim3(256), 0, g.stream,
                      packed_a, static_cast<const T*>(g.a), g.m, g.k, g.lda);
   rc = check_launch("pack_a");
   if (rc) return rc;
