@@ -26,18 +26,23 @@
 namespace mi355x {
 
 // ---------------------------------------------------------------- kernel 1: dequant + pack
-// one thread per shuffled word (kk, n): 8 consecutive k of column n -> one 16-byte slot.
+// one thread per (column, 32-k step): 4 shuffled words (4 x 8 consecutive k of the column) -> the
+// 4 slots the column owns in one piece.  A 256-thread workgroup reads 4 packed rows x 1 KiB
+// (contiguous) and writes 16 complete 1-KiB pieces; scale and zero point are fetched once per
+// thread (group sizes are multiples of 32).
 template <typename T, int ZMODE>
-__global__ void w4_dequant_pack_kernel(T* __restrict__ packed, const uint32_t* __restrict__ qw,
-                                       const T* __restrict__ scales,
-                                       const uint32_t* __restrict__ qz, int n, int k, int group) {
+__global__ __launch_bounds__(256) void w4_dequant_pack_kernel(
+    T* __restrict__ packed, const uint32_t* __restrict__ qw, const T* __restrict__ scales,
+    const uint32_t* __restrict__ qz, int n, int k, int group) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int k8 = k >> 3;
-  if (idx >= (int64_t)k8 * n) return;
-  const int kk = (int)(idx / n);
-  const int col = (int)(idx - (int64_t)kk * n);
-  const int g = (kk * 8) / group;
-  const uint32_t w = qw[idx];
+  const int kt32 = k >> 5;
+  if (idx >= (int64_t)kt32 * n) return;
+  const int kt = (int)(idx / n);
+  const int col = (int)(idx - (int64_t)kt * n);
+  const int g = (kt * 32) / group;
+  uint32_t w[4];
+#pragma unroll
+  for (int lr = 0; lr < 4; ++lr) w[lr] = qw[(int64_t)(kt * 4 + lr) * n + col];
   const float s = to_f32(scales[(int64_t)g * n + col]);
   const uint32_t zw = qz[(int64_t)g * (n >> 3) + (col >> 3)];
   float z;
@@ -46,13 +51,13 @@ __global__ void w4_dequant_pack_kernel(T* __restrict__ packed, const uint32_t* _
   } else {
     z = (float)(((zw >> (4 * (col & 7))) & 0xFu) + 1u);
   }
-  const uint4 v = dequant_word<T>(w, s, -z * s);
-  // destination piece / slot
+  const float zs = -z * s;
+  // destination piece / slots
   const int q = col >> 6, c = (col & 63) >> 2, t = col & 3;
   const int nt = q * 4 + t;
-  const int kt = kk >> 2, lr = kk & 3;
-  uint4* dst = reinterpret_cast<uint4*>(packed) + ((int64_t)nt * (k >> 5) + kt) * 64 + frag_swz(lr, c);
-  *dst = v;
+  uint4* piece = reinterpret_cast<uint4*>(packed) + ((int64_t)nt * kt32 + kt) * 64;
+#pragma unroll
+  for (int lr = 0; lr < 4; ++lr) piece[frag_swz(lr, c)] = dequant_word<T>(w[lr], s, zs);
 }
 
 // (kernel 2, pack_a_kernel: activations -> operand images, lives in w4a16.cuh)
@@ -237,7 +242,7 @@ template <typename T, bool SILU>
 static int run_unfused(const GemmArgs& g) {
   T* packed_b = static_cast<T*>(g.dq_ws);
   T* packed_a = packed_b + (int64_t)g.n * g.k;
-  const int64_t words = (int64_t)(g.k / 8) * g.n;
+  const int64_t words = (int64_t)(g.k / 32) * g.n;   // one thread per (column, 32-k step)
   if (g.zmode == kZeroAwq) {
     hipLaunchKernelGGL((w4_dequant_pack_kernel<T, kZeroAwq>), dim3((words + 255) / 256), dim3(256), 0,
                        g.stream, packed_b, g.qw, static_cast<const T*>(g.scales), g.qz, g.n, g.k,
