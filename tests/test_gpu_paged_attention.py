@@ -177,3 +177,19 @@ def test_paged_attention_full_bench_shape_properties():
     pick = [0, 63]
     ref = R.paged_attention_v1(q[pick], kc, vc, 8, scale, bt[pick], sl[pick], None)
     assert_close_rel(out1[pick], ref, 1e-3, "spot check", abs_floor=_tol(ref))
+
+
+@pytest.mark.parametrize("num_seqs", [24, 110])
+def test_paged_attention_both_workgroup_sizes(num_seqs):
+    """The launcher uses 8-wave workgroups when the grid has < 768 workgroups and 4-wave ones above:
+    24 seqs x 8 kv heads = 192 (v1) / 384 (v2) and 110 x 8 = 880 / 1760 cover both on the
+    Llama-3-8B head shape; results must not depend on it."""
+    random.seed(3)
+    seq_lens = [random.randint(1, 600) for _ in range(num_seqs)]
+    seq_lens[0] = 600
+    args = _setup(num_seqs, 32, 8, 128, 16, torch.bfloat16, seq_lens, seed=5)
+    q, kc, vc, bt, sl, slopes, scale, max_len = args
+    ref1 = R.paged_attention_v1(q, kc, vc, 8, scale, bt, sl, slopes)
+    assert_close_rel(_run_v1(*args, 8, 16), ref1, 1e-3, "v1", abs_floor=_tol(ref1))
+    ref2 = R.paged_attention_v2(q, kc, vc, 8, scale, bt, sl, max_len, slopes)[0]
+    assert_close_rel(_run_v2(*args, 8, 16)[0], ref2, 1e-3, "v2", abs_floor=_tol(ref2))
