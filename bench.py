@@ -114,6 +114,31 @@ def instrument(model, timer: EventTimer):
 
     harness.QLinear.__call__ = timed_linear
 
+    # the fused variants of the same GEMMs (silu epilogue, consumer-side split-K sum) count under
+    # the same kernel names: same weights, same flops, one launch less downstream
+    orig_silu, orig_def = harness.QLinear.silu_mul, harness.QLinear.deferred
+
+    def timed_silu(self, x):
+        m = x.shape[0]
+        flops = 2.0 * m * self.n * self.k
+        nbytes = self.weight_bytes() + 2.0 * m * self.k + 1.0 * m * self.n
+        name = f"{self.quant}_gemm_{'large' if m >= 128 else 'small'}_m"
+        out = timer.time(name, flops, nbytes, lambda: orig_silu(self, x))
+        if out is None and timer.enabled and timer.records and timer.records[-1][0] == name:
+            timer.records.pop()          # fused path not taken: the caller times the plain GEMM
+        return out
+
+    def timed_deferred(self, x):
+        m = x.shape[0]
+        if not (self.quant == "awq" and m <= 64):
+            return orig_def(self, x)     # falls through to __call__, which is timed
+        flops = 2.0 * m * self.n * self.k
+        nbytes = self.weight_bytes() + 2.0 * m * self.k + 2.0 * m * self.n
+        return timer.time(f"{self.quant}_gemm_small_m", flops, nbytes, lambda: orig_def(self, x))
+
+    harness.QLinear.silu_mul = timed_silu
+    harness.QLinear.deferred = timed_deferred
+
     def wrap(opname, cost):
         fn = getattr(ops, opname)
 
@@ -149,6 +174,8 @@ def instrument(model, timer: EventTimer):
          lambda out, q, kc, vc, kvh, scale, bt, sl, bs, max_len, *a, **k:
          cost_decode(out, None, None, None, q, kc, vc, kvh, scale, bt, sl, bs, max_len))
     wrap("fused_add_rms_norm", cost_rows(3, 2))
+    wrap("fused_add_rms_norm_slabs", cost_rows(3, 2))       # (+ sk fp32 slabs when sk > 0)
+    wrap("qkv_rope_cache", cost_rows(1, 1))
     wrap("rms_norm", cost_rows(1, 1))
     wrap("silu_and_mul", cost_rows(2, 1))
     wrap("rotary_embedding", lambda pos, q, k, *a: (0.0, 2.0 * (q.numel() + (k.numel() if k is not None else 0)) * 2))
