@@ -181,6 +181,7 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     const uint4* bbuf = lds + cur * kStage + kBOff + (SILU ? wn * 2 : wn * 4) * 64 + frag;
     // all 12 fragment reads of the stage go out before the first MFMA (the scheduler would
     // otherwise pair each A read with its 4 MFMAs and expose the LDS latency 8 times per stage)
+#ifndef UF_ABLATE_MFMA   // (-DUF_ABLATE_MFMA: copies + barriers only, to measure the fill rate)
     uint4 bf[4], af[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) bf[t] = bbuf[(SILU ? (t < 2 ? t : 6 + t) : t) * 64];
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[i][t] = Mfma<T>::run(af[i], bf[t], acc[i][t]);
     }
+#endif
     cur = cur + 1 == kUfStages ? 0 : cur + 1;
   }
 
