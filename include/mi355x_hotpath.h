@@ -302,6 +302,28 @@ int mi355x_merge_attn_states(void* output, float* output_lse, const void* prefix
                              const float* suffix_lse, int num_tokens, int num_heads, int head_size,
                              int dtype, mi355x_stream stream);
 
+/* ------------------------------------------------------- int8 W8A8 (§8f-4) --
+ * scaled_mm_int8: the int8 branch of cutlass_scaled_mm — out[M,N] (bf16/f16) =
+ *   a_scales . (a[M,K] int8 row-major x b[K,N] int8 COLUMN-major) . b_scales (+ bias[N]), exact
+ *   int32 accumulation, epilogue a_s * (b_s * float(acc)) + bias in fp32, one rounding.
+ *   Arguments as mi355x_scaled_mm_fp8 (workspace: m*n 4-byte elements for the M <= 64 split-K).
+ * ref: csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu:34-39, :84-140; schema
+ *      csrc/torch_bindings.cpp:251-256.
+ * static / dynamic_scaled_int8_quant: q = clamp(rint(x / scale), -127, 127); dynamic computes
+ *   scales[token] = absmax / 127 per row.  Symmetric only (no azp).
+ * ref: csrc/quantization/compressed_tensors/int8_quant_kernels.cu:12-22, :50-68, :94-135. */
+int mi355x_scaled_mm_int8(void* out, const void* a, const void* b, const float* a_scales,
+                          int a_scales_numel, const float* b_scales, int b_scales_numel,
+                          const void* bias, float* workspace, int64_t workspace_elems, int m,
+                          int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype,
+                          mi355x_stream stream);
+int mi355x_static_scaled_int8_quant(void* out, const void* input, const float* scale,
+                                    int num_tokens, int hidden_size, int64_t input_stride,
+                                    int dtype, mi355x_stream stream);
+int mi355x_dynamic_scaled_int8_quant(void* out, const void* input, float* scales, int num_tokens,
+                                     int hidden_size, int64_t input_stride, int dtype,
+                                     mi355x_stream stream);
+
 /* ------------------------------------------------------ decode-step fusions --
  * MI355X-side fusions without a reference op of their own; each is bit-identical to the sequence
  * of reference ops it replaces (tests/test_gpu_w4a16.py, tests/test_gpu_cache_norm_rotary.py).

@@ -510,3 +510,30 @@ def scaled_mm_fp8(a, b, a_scales, b_scales, out_dtype, bias=None) -> torch.Tenso
     if bias is not None:
         o = o + bias.double()
     return o.to(out_dtype)
+
+
+# ======================================================================= int8 W8A8 (§8f-4)
+def scaled_int8_quant(x: torch.Tensor, scale: Optional[torch.Tensor] = None):
+    """csrc/quantization/compressed_tensors/int8_quant_kernels.cu:12-22 (rn: round-half-even, clamp
+    to [-127, 127]), :50-68 (static: x / scale), :94-135 (dynamic per token: scale = absmax / 127,
+    q = rn(x * (127 / absmax)), 0 when absmax == 0).  Returns (int8, scales [T, 1] or the scale)."""
+    xf = x.float()
+    if scale is not None:
+        q = torch.round(xf / scale.float().reshape(()))
+        return q.clamp(-127, 127).to(torch.int8), scale
+    absmax = xf.abs().amax(dim=-1, keepdim=True)
+    # (tensor / tensor: `127.0 / t` is evaluated by torch as t.reciprocal() * 127 — two roundings)
+    inv = torch.where(absmax == 0, torch.zeros_like(absmax), torch.full_like(absmax, 127.0) / absmax)
+    q = torch.round(xf * inv).clamp(-127, 127).to(torch.int8)
+    return q, (absmax / 127.0).reshape(-1, 1)
+
+
+def scaled_mm_int8(a, b, a_scales, b_scales, out_dtype, bias=None) -> torch.Tensor:
+    """The int8 branch of cutlass_scaled_mm (scaled_mm_entry.cu:34-39, :84-140): exact int32
+    accumulation; epilogue in fp32 a_s * (b_s * acc) (+ bias), one rounding (the order of the
+    reference's test-side definition tests/kernels/utils.py baseline_scaled_mm)."""
+    acc = (a.to(torch.int64) @ b.to(torch.int64)).to(torch.float32)       # exact: |acc| < 2^24 here
+    o = a_scales.float().reshape(-1, 1) * (b_scales.float().reshape(1, -1) * acc)
+    if bias is not None:
+        o = o + bias.float()
+    return o.to(out_dtype)

@@ -78,6 +78,6 @@ def test_scaled_mm_fp8_errors():
     with pytest.raises(RuntimeError):
         ops().cutlass_scaled_mm(out, a, b, s, s, None)
     bi = torch.zeros(64, 128, dtype=torch.int8, device=d).t()
-    with pytest.raises(RuntimeError):                        # int8 operands: out of scope
-        ops().cutlass_scaled_mm(out, a.view(torch.int8), bi, s, s, None)
+    with pytest.raises(RuntimeError):                        # mixed operand types
+        ops().cutlass_scaled_mm(out, a, bi, s, s, None)
     assert ops().cutlass_scaled_mm_supports_fp8(90) is True

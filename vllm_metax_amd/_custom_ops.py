@@ -656,6 +656,36 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Te
 
 
 # -------------------------------------------------------------------------- fp8 GEMM
+def scaled_int8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                      azp: Optional[torch.Tensor] = None, symmetric: bool = True):
+    """ref: vllm._custom_ops.scaled_int8_quant -> torch.ops._C.static_scaled_int8_quant /
+    dynamic_scaled_int8_quant (csrc/quantization/compressed_tensors/int8_quant_kernels.cu).
+    Returns (int8 tensor, scales, None).  static when `scale` is given (one fp32 value), else
+    dynamic per token.  Symmetric only."""
+    if azp is not None or not symmetric:
+        raise NotImplementedError("scaled_int8_quant: the asymmetric (azp) variants are not implemented")
+    _dev(input)
+    if input.stride(-1) != 1:
+        raise RuntimeError("scaled_int8_quant: input must have unit inner stride")
+    hidden = input.size(-1)
+    tokens = input.numel() // hidden if hidden else 0
+    in_stride = input.stride(-2) if input.dim() >= 2 else hidden
+    out = torch.empty(input.shape, dtype=torch.int8, device=input.device)
+    if scale is not None:
+        _dev(scale)
+        if scale.numel() != 1 or scale.dtype != torch.float32:
+            raise RuntimeError("scaled_int8_quant: static scale must be one float32 value")
+        rc = _abi.load().mi355x_static_scaled_int8_quant(_ptr(out), _ptr(input), _ptr(scale), tokens,
+                                                         hidden, in_stride, _dt(input), _stream())
+        _abi.check(rc, "static_scaled_int8_quant")
+        return out, scale, None
+    scales = torch.empty((tokens, 1), dtype=torch.float32, device=input.device)
+    rc = _abi.load().mi355x_dynamic_scaled_int8_quant(_ptr(out), _ptr(input), _ptr(scales), tokens,
+                                                      hidden, in_stride, _dt(input), _stream())
+    _abi.check(rc, "dynamic_scaled_int8_quant")
+    return out, scales, None
+
+
 def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:
     """The reference returns False (scaled_mm_entry.cu:22-24); gfx950 has OCP-fp8 MFMA."""
     return True
@@ -676,9 +706,8 @@ def cutlass_scaled_mm(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
         raise RuntimeError("cutlass_scaled_mm: b must be column-major")
     if out.stride(0) % 16 or b.stride(1) % 16:
         raise RuntimeError("cutlass_scaled_mm: 16-byte alignment required")
-    if a.dtype != torch.float8_e4m3fn or b.dtype != torch.float8_e4m3fn:
-        raise RuntimeError("cutlass_scaled_mm: only float8_e4m3fn operands are supported "
-                           "(the int8 branch is out of scope, SURVEY §8f-4)")
+    if a.dtype != b.dtype or a.dtype not in (torch.float8_e4m3fn, torch.int8):
+        raise RuntimeError("cutlass_scaled_mm: a and b must both be float8_e4m3fn or both int8")
     m, k = a.shape
     n = b.size(1)
     if a_scales.numel() not in (1, m) or b_scales.numel() not in (1, n):
@@ -691,7 +720,8 @@ def cutlass_scaled_mm(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
         raise RuntimeError("cutlass_scaled_mm: bad bias")
     # small-M (decode) shapes split K across workgroups through an fp32 workspace
     ws = torch.empty((m, n), dtype=torch.float32, device=a.device) if m <= 64 else None
-    rc = _abi.load().mi355x_scaled_mm_fp8(
+    fn = _abi.load().mi355x_scaled_mm_int8 if a.dtype == torch.int8 else _abi.load().mi355x_scaled_mm_fp8
+    rc = fn(
         _ptr(out), _ptr(a), _ptr(b), _ptr(a_scales), a_scales.numel(), _ptr(b_scales),
         b_scales.numel(), _ptr(bias), _ptr(ws), ws.numel() if ws is not None else 0, m, n, k,
         a.stride(0), b.stride(1), out.stride(0), _dt(out), _stream())

@@ -18,13 +18,41 @@
 //             ds_read_b128), issue-early / write-late double buffering, XCD-aware tiles.
 //   small M : 64 x 64 tile, the 4 waves split K and are summed through LDS; optional
 //             split-K across workgroups through an fp32 workspace.
+//
+// int8 (W8A8): the SAME kernels instantiated with v_mfma_i32_16x16x32_i8 —
+// identical operand shape (8 consecutive-k bytes per lane), exact int32 accumulation (split-K
+// through int32 atomics), epilogue out = T(a_s * (b_s * float(acc)) + bias) in fp32 — the
+// reference's int8 cutlass_scaled_mm (csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu:34-39,
+// :84-140; epilogue order as tests/kernels/utils.py baseline_scaled_mm).
 #include "common.cuh"
 
 namespace mi355x {
 
-__device__ __forceinline__ f32x4_t mfma_fp8(uint64_t a, uint64_t b, f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)a, (long)b, c, 0, 0, 0);
-}
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+struct OpFp8 {
+  typedef f32x4_t acc_t;
+  typedef float elem_t;
+  static __device__ __forceinline__ acc_t run(uint64_t a, uint64_t b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)a, (long)b, c, 0, 0, 0);
+  }
+  // (a_s . A)(b_s . B) + bias, the order the fp8 oracle uses
+  static __device__ __forceinline__ float finish(float acc, float as, float bs, float bi) {
+    return acc * as * bs + bi;
+  }
+};
+struct OpI8 {
+  typedef i32x4_t acc_t;
+  typedef int elem_t;
+  static __device__ __forceinline__ acc_t run(uint64_t a, uint64_t b, acc_t c) {
+    return __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a, (long)b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ float finish(int acc, float as, float bs, float bi) {
+#pragma clang fp contract(off)
+    const float v = as * (bs * (float)acc);
+    return v + bi;
+  }
+};
 
 template <typename T>
 __device__ __forceinline__ T out_cast(float v) {
@@ -52,7 +80,7 @@ constexpr int kF8BM = 128;
 constexpr int kF8BN = 256;
 constexpr int kF8BK = 64;  // bytes of K per tile
 
-template <typename T>
+template <typename T, typename Op>
 __global__ __launch_bounds__(256, 2) void fp8_gemm_large_kernel(
     T* __restrict__ out, const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
     const float* __restrict__ a_scales, int a_per_row, const float* __restrict__ b_scales,
@@ -95,11 +123,11 @@ __global__ __launch_bounds__(256, 2) void fp8_gemm_large_kernel(
     b_src[t] = b + (int64_t)col * ldb + 16 * lr;
   }
 
-  f32x4_t acc[8][4];
+  typename Op::acc_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) acc[i][t] = typename Op::acc_t{0, 0, 0, 0};
   }
 
   uint4 a_stage[2], b_cur[4], b_nxt[4];
@@ -139,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void fp8_gemm_large_kernel(
         for (int t = 0; t < 4; ++t) {
           const uint64_t b0 = ((uint64_t)b_cur[t].y << 32) | b_cur[t].x;
           const uint64_t b1 = ((uint64_t)b_cur[t].w << 32) | b_cur[t].z;
-          acc[i][t] = mfma_fp8(a0, b0, acc[i][t]);
-          acc[i][t] = mfma_fp8(a1, b1, acc[i][t]);
+          acc[i][t] = Op::run(a0, b0, acc[i][t]);
+          acc[i][t] = Op::run(a1, b1, acc[i][t]);
         }
       }
     }
@@ -167,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void fp8_gemm_large_kernel(
         const int row = mb * kF8BM + i * 16 + 4 * lr + j;
         if (row < m) {
           const float as = a_scales[a_per_row ? row : 0];
-          out[(int64_t)row * ldc + col] = out_cast<T>(acc[i][t][j] * as * bs + bi);
+          out[(int64_t)row * ldc + col] = out_cast<T>(Op::finish(acc[i][t][j], as, bs, bi));
         }
       }
     }
@@ -175,14 +203,15 @@ __global__ __launch_bounds__(256, 2) void fp8_gemm_large_kernel(
 }
 
 // ------------------------------------------------------------------------- small M
-template <typename T, int MT>
+template <typename T, int MT, typename Op>
 __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
-    T* __restrict__ out, float* __restrict__ ws, const uint8_t* __restrict__ a,
+    T* __restrict__ out, typename Op::elem_t* __restrict__ ws, const uint8_t* __restrict__ a,
     const uint8_t* __restrict__ b, const float* __restrict__ a_scales, int a_per_row,
     const float* __restrict__ b_scales, int b_per_col, const T* __restrict__ bias, int m, int n,
     int k, int64_t lda, int64_t ldb, int64_t ldc, int ktiles_per_split) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem);  // [2][MT*16][64]
+  typedef typename Op::elem_t elem_t;
+  elem_t* red = reinterpret_cast<elem_t*>(smem);  // [2][MT*16][64]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int lc = lane & 15;
@@ -206,11 +235,11 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
     col = col < n ? col : n - 1;
     b_src[t] = b + (int64_t)col * ldb + 16 * lr;
   }
-  f32x4_t acc[MT][4];
+  typename Op::acc_t acc[MT][4];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[i][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) acc[i][t] = typename Op::acc_t{0, 0, 0, 0};
   }
   for (int kt = kt_begin + wave; kt < kt_end; kt += 4) {
     uint4 af[MT], bf[4];
@@ -226,13 +255,13 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
       for (int t = 0; t < 4; ++t) {
         const uint64_t b0 = ((uint64_t)bf[t].y << 32) | bf[t].x;
         const uint64_t b1 = ((uint64_t)bf[t].w << 32) | bf[t].z;
-        acc[i][t] = mfma_fp8(a0, b0, acc[i][t]);
-        acc[i][t] = mfma_fp8(a1, b1, acc[i][t]);
+        acc[i][t] = Op::run(a0, b0, acc[i][t]);
+        acc[i][t] = Op::run(a1, b1, acc[i][t]);
       }
     }
   }
   // cross-wave tree reduction through LDS: element (row, col) at red[row*64 + col]
-  auto lds_store = [&](float* dst) {
+  auto lds_store = [&](elem_t* dst) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[(i * 16 + 4 * lr + j) * 64 + 16 * t + lc] = acc[i][t][j];
   };
-  auto lds_add = [&](const float* src) {
+  auto lds_add = [&](const elem_t* src) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
         if (row >= m) continue;
         if (gridDim.y == 1) {
           const float as = a_scales[a_per_row ? row : 0];
-          out[(int64_t)row * ldc + col] = out_cast<T>(acc[i][t][j] * as * bs + bi);
+          out[(int64_t)row * ldc + col] = out_cast<T>(Op::finish(acc[i][t][j], as, bs, bi));
         } else {
           atomicAdd(ws + (int64_t)row * n + col, acc[i][t][j]);
         }
@@ -282,21 +311,20 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
 }
 
 // split-K epilogue: out = T(ws * a_s * b_s + bias)
-template <typename T>
-__global__ void fp8_gemm_finish_kernel(T* __restrict__ out, const float* __restrict__ ws,
+template <typename T, typename Op>
+__global__ void fp8_gemm_finish_kernel(T* __restrict__ out, const typename Op::elem_t* __restrict__ ws,
                                        const float* __restrict__ a_scales, int a_per_row,
                                        const float* __restrict__ b_scales, int b_per_col,
                                        const T* __restrict__ bias, int m, int n, int64_t ldc) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   const int row = blockIdx.y;
   if (col >= n) return;
-  const float v = ws[(int64_t)row * n + col] * a_scales[a_per_row ? row : 0] *
-                      b_scales[b_per_col ? col : 0] +
-                  (bias ? to_f32(bias[col]) : 0.f);
+  const float v = Op::finish(ws[(int64_t)row * n + col], a_scales[a_per_row ? row : 0],
+                             b_scales[b_per_col ? col : 0], bias ? to_f32(bias[col]) : 0.f);
   out[(int64_t)row * ldc + col] = out_cast<T>(v);
 }
 
-template <typename T>
+template <typename T, typename Op>
 static int run_fp8(const Fp8Args& g) {
   const int a_per_row = g.a_scales_numel > 1;
   const int b_per_col = g.b_scales_numel > 1;
@@ -306,7 +334,7 @@ static int run_fp8(const Fp8Args& g) {
     const int num_m_blocks = (g.m + kF8BM - 1) / kF8BM;
     const int num_n_blocks = (g.n + kF8BN - 1) / kF8BN;
     const int num_tiles = num_m_blocks * num_n_blocks;
-    hipLaunchKernelGGL(fp8_gemm_large_kernel<T>, dim3(num_tiles), dim3(256),
+    hipLaunchKernelGGL((fp8_gemm_large_kernel<T, Op>), dim3(num_tiles), dim3(256),
                        (size_t)2 * 8 * 64 * sizeof(uint4), g.stream, out, g.a, g.b, g.a_scales,
                        a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.k, g.lda, g.ldb, g.ldc,
                        num_m_blocks, num_tiles);
@@ -330,8 +358,9 @@ static int run_fp8(const Fp8Args& g) {
   const int mt = (g.m + 15) / 16;
   dim3 grid(col_tiles, sk), block(256);
 #define LAUNCH_F8S(MTV)                                                                       \
-  hipLaunchKernelGGL((fp8_gemm_small_kernel<T, MTV>), grid, block,                            \
-                     (size_t)2 * MTV * 16 * 64 * sizeof(float), g.stream, out, g.ws, g.a, g.b, \
+  hipLaunchKernelGGL((fp8_gemm_small_kernel<T, MTV, Op>), grid, block,                        \
+                     (size_t)2 * MTV * 16 * 64 * sizeof(float), g.stream, out,                 \
+                     reinterpret_cast<typename Op::elem_t*>(g.ws), g.a, g.b,                   \
                      g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.k, g.lda, \
                      g.ldb, g.ldc, per_split)
   if (mt <= 1) LAUNCH_F8S(1);
@@ -340,8 +369,8 @@ static int run_fp8(const Fp8Args& g) {
 #undef LAUNCH_F8S
   int rc = check_launch("scaled_mm_fp8(small)");
   if (rc || sk == 1) return rc;
-  hipLaunchKernelGGL(fp8_gemm_finish_kernel<T>, dim3((g.n + 255) / 256, g.m), dim3(256), 0,
-                     g.stream, out, g.ws, g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m,
+  hipLaunchKernelGGL((fp8_gemm_finish_kernel<T, Op>), dim3((g.n + 255) / 256, g.m), dim3(256), 0,
+                     g.stream, out, reinterpret_cast<const typename Op::elem_t*>(g.ws), g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m,
                      g.n, g.ldc);
   return check_launch("scaled_mm_fp8(finish)");
 }
@@ -371,5 +400,29 @@ extern "C" int mi355x_scaled_mm_fp8(void* out, const void* a, const void* b,
   Fp8Args g{out, static_cast<const uint8_t*>(a), static_cast<const uint8_t*>(b), a_scales,
             a_scales_numel, b_scales, b_scales_numel, bias, m, n, k, lda, ldb, ldc, workspace,
             workspace_elems, static_cast<hipStream_t>(stream)};
-  return MI355X_DISPATCH_HALF(out_dtype, [&] { return run_fp8<scalar_t>(g); });
+  return MI355X_DISPATCH_HALF(out_dtype, [&] { return run_fp8<scalar_t, OpFp8>(g); });
+}
+
+extern "C" int mi355x_scaled_mm_int8(void* out, const void* a, const void* b,
+                                     const float* a_scales, int a_scales_numel,
+                                     const float* b_scales, int b_scales_numel,
+                                     const void* bias, float* workspace,
+                                     int64_t workspace_elems, int m, int n, int k, int64_t lda,
+                                     int64_t ldb, int64_t ldc, int out_dtype,
+                                     mi355x_stream stream) {
+  MI355X_REQUIRE(m >= 0 && n > 0 && k > 0, MI355X_EINVAL, "scaled_mm_int8: bad sizes");
+  MI355X_REQUIRE(k % 64 == 0, MI355X_EUNSUPPORTED, "scaled_mm_int8: k = %d must be a multiple of 64", k);
+  MI355X_REQUIRE(lda % 16 == 0 && ldb % 16 == 0, MI355X_EUNSUPPORTED,
+                 "scaled_mm_int8: lda / ldb must be multiples of 16 bytes");
+  MI355X_REQUIRE((a_scales_numel == 1 || a_scales_numel == m) &&
+                     (b_scales_numel == 1 || b_scales_numel == n),
+                 MI355X_EINVAL, "scaled_mm_int8: scales must be per-tensor or per-row / per-column");
+  if (m == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && a && b && a_scales && b_scales, MI355X_EINVAL, "scaled_mm_int8: null pointer");
+  MI355X_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0,
+                 MI355X_EUNSUPPORTED, "scaled_mm_int8: a and b must be 16-byte aligned");
+  Fp8Args g{out, static_cast<const uint8_t*>(a), static_cast<const uint8_t*>(b), a_scales,
+            a_scales_numel, b_scales, b_scales_numel, bias, m, n, k, lda, ldb, ldc, workspace,
+            workspace_elems, static_cast<hipStream_t>(stream)};
+  return MI355X_DISPATCH_HALF(out_dtype, [&] { return run_fp8<scalar_t, OpI8>(g); });
 }

@@ -354,9 +354,9 @@ void cutlass_scaled_mm(Tensor& out, const Tensor& a, const Tensor& b, const Tens
   TORCH_CHECK(a.stride(1) == 1 && out.stride(1) == 1);  // row-major
   TORCH_CHECK(b.stride(0) == 1);                         // column-major
   TORCH_CHECK(out.stride(0) % 16 == 0 && b.stride(1) % 16 == 0);
-  TORCH_CHECK(a.scalar_type() == at::kFloat8_e4m3fn && b.scalar_type() == at::kFloat8_e4m3fn,
-              "cutlass_scaled_mm: only float8_e4m3fn operands are supported on MI355X "
-              "(the int8 branch is out of scope)");
+  const bool is_i8 = a.scalar_type() == at::kChar;
+  TORCH_CHECK(a.scalar_type() == b.scalar_type() && (is_i8 || a.scalar_type() == at::kFloat8_e4m3fn),
+              "cutlass_scaled_mm: a and b must both be int8 or both float8_e4m3fn");
   const int64_t m = a.size(0), k = a.size(1), n = b.size(1);
   TORCH_CHECK(a_scales.numel() == 1 || a_scales.numel() == m);
   TORCH_CHECK(b_scales.numel() == 1 || b_scales.numel() == n);
@@ -369,16 +369,42 @@ void cutlass_scaled_mm(Tensor& out, const Tensor& a, const Tensor& b, const Tens
   Guard g(a);
   Tensor ws;  // small-M (decode) shapes split K across workgroups through an fp32 workspace
   if (m <= 64 && m > 0) ws = at::empty({m, n}, a.options().dtype(at::kFloat));
-  ok(mi355x_scaled_mm_fp8(out.data_ptr(), a.data_ptr(), b.data_ptr(), a_scales.data_ptr<float>(),
-                          a_scales.numel(), b_scales.data_ptr<float>(), b_scales.numel(),
-                          (bias.has_value() && bias->defined()) ? bias->data_ptr() : nullptr,
-                          ws.defined() ? ws.data_ptr<float>() : nullptr,
-                          ws.defined() ? ws.numel() : 0, m, n, k, a.stride(0), b.stride(1),
-                          out.stride(0), dt(out), stream_of(a)),
+  auto fn = is_i8 ? mi355x_scaled_mm_int8 : mi355x_scaled_mm_fp8;   // scaled_mm_entry.cu:34-39 / new
+  ok(fn(out.data_ptr(), a.data_ptr(), b.data_ptr(), a_scales.data_ptr<float>(), a_scales.numel(),
+        b_scales.data_ptr<float>(), b_scales.numel(),
+        (bias.has_value() && bias->defined()) ? bias->data_ptr() : nullptr,
+        ws.defined() ? ws.data_ptr<float>() : nullptr, ws.defined() ? ws.numel() : 0, m, n, k,
+        a.stride(0), b.stride(1), out.stride(0), dt(out), stream_of(a)),
      "cutlass_scaled_mm");
 }
 
 bool cutlass_scaled_mm_supports_fp8(int64_t cuda_device_capability) { return true; }
+
+// ------------------------------------------------------------------ int8 quant
+// ref: csrc/quantization/compressed_tensors/int8_quant_kernels.cu (launchers), schema
+// torch_bindings.cpp:349-360.  Symmetric only: azp must be absent.
+void static_scaled_int8_quant(Tensor& out, const Tensor& input, const Tensor& scale,
+                              const std::optional<Tensor>& azp) {
+  TORCH_CHECK(input.is_contiguous() && out.is_contiguous());
+  TORCH_CHECK(scale.numel() == 1);
+  TORCH_CHECK(!azp.has_value() || !azp->defined(), "static_scaled_int8_quant: azp is not implemented");
+  Guard g(input);
+  ok(mi355x_static_scaled_int8_quant(out.data_ptr(), input.data_ptr(), scale.data_ptr<float>(),
+                                     rows(input), input.size(-1), input.size(-1), dt(input),
+                                     stream_of(input)),
+     "static_scaled_int8_quant");
+}
+
+void dynamic_scaled_int8_quant(Tensor& out, const Tensor& input, Tensor& scales,
+                               const std::optional<Tensor>& azp) {
+  TORCH_CHECK(input.is_contiguous() && out.is_contiguous() && scales.is_contiguous());
+  TORCH_CHECK(!azp.has_value() || !azp->defined(), "dynamic_scaled_int8_quant: azp is not implemented");
+  Guard g(input);
+  ok(mi355x_dynamic_scaled_int8_quant(out.data_ptr(), input.data_ptr(), scales.data_ptr<float>(),
+                                      rows(input), input.size(-1), input.size(-1), dt(input),
+                                      stream_of(input)),
+     "dynamic_scaled_int8_quant");
+}
 
 // ------------------------------------------------------------------- fp8 quant
 void static_scaled_fp8_quant(Tensor& out, const Tensor& input, const Tensor& scale) {
@@ -589,6 +615,15 @@ TORCH_LIBRARY(_C, ops) {
 
   ops.def("awq_to_gptq_4bit(Tensor qweight) -> Tensor");
   ops.impl("awq_to_gptq_4bit", c10::kCUDA, &awq_to_gptq_4bit);
+
+  ops.def(
+      "static_scaled_int8_quant(Tensor! result, Tensor input, Tensor scale,"
+      "Tensor? azp) -> ()");
+  ops.impl("static_scaled_int8_quant", c10::kCUDA, &static_scaled_int8_quant);
+  ops.def(
+      "dynamic_scaled_int8_quant(Tensor! result, Tensor input, Tensor! scale, "
+      "Tensor!? azp) -> ()");
+  ops.impl("dynamic_scaled_int8_quant", c10::kCUDA, &dynamic_scaled_int8_quant);
 
   ops.def(
       "cutlass_scaled_mm(Tensor! out, Tensor a,"
