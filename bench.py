@@ -42,6 +42,8 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+WEIGHT_FORMAT = {"awq": "w4a16 g128", "gptq": "w4a16 g128", "fp8": "w8a8 fp8", "int8": "w8a8 int8",
+                 "none": "bf16"}
 
 
 def parse_args():
@@ -49,7 +51,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--quant", default="awq", choices=["awq", "gptq", "fp8", "none"])
+    ap.add_argument("--quant", default="awq", choices=["awq", "gptq", "fp8", "int8", "none"])
     ap.add_argument("--model", default="llama-3-8b", choices=["llama-3-8b", "tiny"])
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--input-len", type=int, default=1024)
@@ -408,9 +410,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak" if tp == 1 else "strong",
         "vs_baseline": None,
-        "dtype": "bf16" if args.quant != "fp8" else "fp8",
+        "dtype": {"fp8": "fp8", "int8": "int8"}.get(args.quant, "bf16"),
         "data": "synthetic",
-        "config": {"workload": f"{cfg.name}-{args.quant} w4a16 g128: prefill {args.batch}x{args.input_len} "
+        "config": {"workload": f"{cfg.name}-{args.quant} {WEIGHT_FORMAT.get(args.quant, args.quant)}: prefill {args.batch}x{args.input_len} "
                                f"in chunks of {args.chunk_seqs} seqs + {args.output_len - 1} graph-replayed "
                                f"decode steps (1 step = 1 whole job)",
                    "batch": args.batch, "global_batch": args.batch * replicas,

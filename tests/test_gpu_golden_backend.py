@@ -310,3 +310,30 @@ def test_end_to_end_tiny_model_vs_oracle():
         # greedy tokens: equal wherever the oracle's top-2 logit margin is not a near-tie
         agree = sum(int((g == r).sum()) for g, r in zip(got, ref_tok))
         assert agree >= 11, (got, ref_tok)      # 12 tokens; allow one bf16 near-tie flip
+
+
+@pytest.mark.parametrize("quant", ["int8", "fp8", "gptq"])
+def test_end_to_end_tiny_model_other_quant_modes_run_and_agree_eager_vs_graph(quant):
+    """The same serving loop with the W8A8 / fp8 / GPTQ linears: finite logits path, and the
+    HIP-graph replay reproduces the eager tokens exactly (same kernels, same order)."""
+    from vllm_metax_amd import harness
+    torch.manual_seed(0)
+    cfg = harness.ModelConfig.tiny(quant)
+    model = harness.HotPathModel(cfg, 3, 64, device="cuda:0", seed=0)
+    model.setup_decode(3, 40, 64)
+    tokens = torch.randint(0, cfg.vocab, (3, 40), device=model.device)
+    runs = []
+    for use_graph in (False, True):
+        for kc, vc in zip(model.k_cache, model.v_cache):
+            kc.zero_(); vc.zero_()
+        first = model.prefill(tokens, [0, 1, 2], 0)
+        got = [first.cpu()]
+        model.d_tokens.copy_(first)
+        model.set_decode_lengths(torch.full((3,), 40, device=model.device))
+        model._graph = None
+        for _ in range(3):
+            model.decode_step(use_graph=use_graph)
+            got.append(model.d_tokens.cpu().clone())
+        runs.append(torch.stack(got))
+    assert torch.equal(runs[0], runs[1])
+    assert int(runs[0].min()) >= 0 and int(runs[0].max()) < cfg.vocab

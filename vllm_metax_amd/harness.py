@@ -36,7 +36,7 @@ class ModelConfig:
     vocab: int = 128256
     rope_theta: float = 500000.0
     eps: float = 1e-5
-    quant: str = "awq"          # "awq" | "gptq" | "fp8" | "none"
+    quant: str = "awq"          # "awq" | "gptq" | "fp8" | "int8" | "none"
     group_size: int = 128
     tp: int = 1                 # tensor-parallel degree (heads / ffn sharded, all-reduce after o/down)
 
@@ -87,6 +87,11 @@ class QLinear:
             w = torch.randn(n, k, device=device, generator=gen).clamp_(-448, 448)
             self.weight = w.to(torch.float8_e4m3fn).t()                  # [K, N] column-major
             self.w_scale = (torch.rand(1, n, device=device, generator=gen) * 4e-3 + 1e-3)
+        elif cfg.quant == "int8":
+            # W8A8 (compressed-tensors style): per-channel int8 weights, dynamic per-token activations
+            w = torch.randint(-127, 128, (n, k), dtype=torch.int32, device=device, generator=gen)
+            self.weight = w.to(torch.int8).t()                            # [K, N] column-major
+            self.w_scale = (torch.rand(1, n, device=device, generator=gen) * 4e-5 + 1e-5)
         else:
             self.weight = (torch.randn(k, n, device=device, generator=gen) * 0.02).to(dtype)
         self._ws = {}
@@ -121,6 +126,11 @@ class QLinear:
             out = torch.empty(m, self.n, dtype=x.dtype, device=x.device)
             ops.cutlass_scaled_mm(out, xq, self.weight, xs, self.w_scale, None)
             return out
+        if self.quant == "int8":
+            xq, xs, _ = ops.scaled_int8_quant(x)
+            out = torch.empty(m, self.n, dtype=x.dtype, device=x.device)
+            ops.cutlass_scaled_mm(out, xq, self.weight, xs, self.w_scale, None)
+            return out
         return torch.matmul(x, self.weight)
 
     def silu_mul(self, x: torch.Tensor):
@@ -143,7 +153,7 @@ class QLinear:
         if self.quant in ("awq", "gptq"):
             return self.k * self.n // 2 + (self.k // self.group) * self.n * 2 \
                 + (self.k // self.group) * self.n // 2
-        if self.quant == "fp8":
+        if self.quant in ("fp8", "int8"):
             return self.k * self.n + self.n * 4
         return self.k * self.n * 2
 
