@@ -8,7 +8,7 @@ per-channel scales, optional bias); tolerance: one output ulp + 2e-4 * max|ref| 
 reference test uses rtol 5e-1 / atol 1.5e-1; north_star asks <= 1e-3 rel).
 
 Fraction of elements allowed to differ from the exactly rounded result: 12 %.  Measured on
-MI355X (scripts/exp_fp8_accum.py, profiles/r01_fp8_accum.txt): v_mfma_f32_16x16x32_fp8_fp8 is
+MI355X (tests/diag_fp8_accum.py, profiles/r01_fp8_accum.txt): v_mfma_f32_16x16x32_fp8_fp8 is
 exact on integer-valued operands but on random e4m3 operands 4.7 % (K=64) .. 6.5 % (K=4096) of
 fp16-rounded outputs differ by one ulp from the exactly rounded sum — the MFMA's internal
 32-term adder does not keep full fp32 alignment.  That is a property of the hardware unit,
