@@ -100,3 +100,11 @@ def test_harness_accounting_matches_baseline_md():
     assert abs(meta - 4.3e6) / 4.3e6 < 0.05
     kv = 64 * 1088 * cfg.kv_heads * cfg.head_dim * 2 * 2
     assert abs(kv - 285e6) / 285e6 < 0.01
+
+
+def test_decode_kernel_choice_follows_the_upstream_rule():
+    from vllm_metax_amd.attention.backend import use_paged_attention_v1
+    assert use_paged_attention_v1(64, 32, 1152)          # bench shape: 2048 (seq, head) pairs
+    assert use_paged_attention_v1(1, 32, 400)            # one partition
+    assert not use_paged_attention_v1(4, 32, 1152)       # few pairs, 3 partitions -> v2
+    assert not use_paged_attention_v1(256, 32, 9000)     # too long for one workgroup's LDS

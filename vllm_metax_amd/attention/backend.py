@@ -110,6 +110,14 @@ def split_kv_cache(kv_cache: torch.Tensor, num_kv_heads: int, head_size: int):
     return key_cache, value_cache
 
 
+def use_paged_attention_v1(num_seqs: int, num_heads: int, max_seq_len: int) -> bool:
+    """The v1 / v2 choice of the upstream caller (vllm/attention/ops/paged_attn.py,
+    PagedAttention.forward_decode): v1 when the context fits one workgroup's LDS and either a single
+    512-token partition covers it or there are already > 512 (sequence, head) pairs to spread."""
+    max_parts = (max_seq_len + 511) // 512
+    return max_seq_len <= 8192 and (max_parts == 1 or num_seqs * num_heads > 512)
+
+
 def decode_attention(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torch.Tensor,
                      tmp_out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
                      value_cache: torch.Tensor, num_kv_heads: int, scale: float,
@@ -120,10 +128,7 @@ def decode_attention(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torc
     short enough for one workgroup's LDS and there is already enough parallelism without
     partitioning (num_seqs * num_heads > 512), else the 512-token-partition kernel + reduce.
     Measured at 64 seqs x 32 heads, ctx 1088: v1 63.9 us, v2 67.1 us (scripts/bench_attn.py)."""
-    num_seqs, num_heads = query.shape[0], query.shape[1]
-    max_parts = (max_seq_len + 511) // 512
-    use_v1 = max_seq_len <= 8192 and (max_parts == 1 or num_seqs * num_heads > 512)
-    if use_v1:
+    if use_paged_attention_v1(query.shape[0], query.shape[1], max_seq_len):
         ops.paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale, block_table,
                                seq_lens, block_size, max_seq_len, alibi_slopes, "auto")
     else:
