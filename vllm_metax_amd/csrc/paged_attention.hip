@@ -166,6 +166,20 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   float qk_max[GT];
 #pragma unroll
   for (int g = 0; g < GT; ++g) qk_max[g] = -3.402823466e+38f;
+  // fast path: i-th work item of this wave = two consecutive blocks while whole rounds of
+  // 2*nwaves blocks last, then single blocks
+  const int nblk_part = end_block - start_block;
+  const int full_rounds = nblk_part / (2 * nwaves);
+  auto work_item = [&](int i, int& blk, bool& two) {
+    if (i < full_rounds) {
+      blk = start_block + (i * nwaves + wave) * 2;
+      two = true;
+      return true;
+    }
+    blk = start_block + full_rounds * 2 * nwaves + (i - full_rounds) * nwaves + wave;
+    two = false;
+    return blk < end_block;
+  };
 
   if constexpr (HS != 0) {
     // q chunks of this lane live in registers for the whole kernel
@@ -179,9 +193,13 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
                              : make_uint4(0, 0, 0, 0);
       }
     }
-    // two blocks per iteration and wave -> 2*NI 16-B loads in flight per lane
-    for (int blk = start_block + wave * 2; blk < end_block; blk += nwaves * 2) {
-      const bool has2 = (blk + 1) < end_block;
+    // two blocks per iteration and wave -> 2*NI 16-B loads in flight per lane; the blocks that do
+    // not fill a whole round of 2*nwaves go one per wave (72 blocks on 8 waves: 4 rounds + 8
+    // singles, not 5 iterations for half of the waves and 4 for the rest)
+    for (int it = 0;; ++it) {
+      int blk;
+      bool has2;
+      if (!work_item(it, blk, has2)) break;
       const int64_t pb0 = block_table[blk];
       const int64_t pb1 = has2 ? block_table[blk + 1] : pb0;
       const T* kp0 = k_cache + pb0 * kv_block_stride + (int64_t)kv_head * kv_head_stride;
@@ -285,9 +303,12 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   };
   uint4 vpre0[NIV], vpre1[NIV];
   if constexpr (HS != 0) {
-    const int blk = start_block + wave * 2;
-    if (blk < end_block) load_v(blk, vpre0);
-    if (blk + 1 < end_block) load_v(blk + 1, vpre1);
+    int blk;
+    bool two;
+    if (work_item(0, blk, two)) {
+      load_v(blk, vpre0);
+      if (two) load_v(blk + 1, vpre1);
+    }
   }
 
   // =========================== softmax ===========================================
@@ -352,13 +373,17 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   };
 
   if constexpr (HS != 0) {
-    // software pipeline: the loads of iteration i+1 are issued before the math of iteration i
-    for (int blk = start_block + wave * 2; blk < end_block; blk += nwaves * 2) {
-      const bool has2 = (blk + 1) < end_block;
-      const int nb = blk + nwaves * 2;
+    // software pipeline: the loads of work item i+1 are issued before the math of item i
+    for (int it = 0;; ++it) {
+      int blk, nblk2;
+      bool has2, nhas2;
+      if (!work_item(it, blk, has2)) break;
+      const bool more = work_item(it + 1, nblk2, nhas2);
       uint4 n0[NIV], n1[NIV];
-      if (nb < end_block) load_v(nb, n0);
-      if (nb + 1 < end_block) load_v(nb + 1, n1);
+      if (more) {
+        load_v(nblk2, n0);
+        if (nhas2) load_v(nblk2 + 1, n1);
+      }
       pv_block(blk, vpre0);
       if (has2) pv_block(blk + 1, vpre1);
 #pragma unroll
