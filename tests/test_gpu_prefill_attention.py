@@ -101,3 +101,43 @@ def test_prefill_matches_decode_kernel_on_last_token():
     eps = 2.0 ** -7
     assert_close_rel(out[last], dec, 2e-3, "prefill vs decode", abs_floor=eps * dec.float().abs().max().item())
     assert torch.isfinite(out.float()).all()
+
+
+def test_prefill_bench_chunk_properties_at_full_size():
+    """BASELINE chunk shape (8 sequences x 1024 new tokens, 32 / 8 heads, d 128) — too large for the
+    oracle, so size-independent properties: (a) sequences are independent: the batched launch equals
+    eight single-sequence launches bit for bit; (b) causality: the first 512 rows of a 1024-token
+    prefill equal a 512-token prefill of the same sequence bit for bit; (c) the launch order
+    (heaviest query block first) does not leak into the result: permuting the sequences permutes the
+    output."""
+    torch.manual_seed(11)
+    d = dev()
+    S, L, H, KVH, D, BS = 8, 1024, 32, 8, 128, 16
+    nblk = L // BS
+    nb = S * nblk
+    kc = (torch.randn(nb, KVH, D // 8, BS, 8, device=d) * 0.3).to(torch.bfloat16)
+    vc = (torch.randn(nb, KVH, D, BS, device=d) * 0.3).to(torch.bfloat16)
+    q = (torch.randn(S * L, H, D, device=d) * 0.5).to(torch.bfloat16)
+    bt = torch.randperm(nb, device=d).to(torch.int32).view(S, nblk)
+    sl = torch.full((S,), L, device=d, dtype=torch.int32)
+    cu = torch.arange(S + 1, device=d, dtype=torch.int32) * L
+    scale = D ** -0.5
+    out = torch.empty_like(q)
+    ops().paged_prefill_attention(out, q, kc, vc, KVH, scale, bt, sl, cu, L, BS)
+    assert torch.isfinite(out.float()).all()
+    one_cu = torch.tensor([0, L], device=d, dtype=torch.int32)
+    for s in (0, 3, 7):
+        o1 = torch.empty(L, H, D, dtype=torch.bfloat16, device=d)
+        ops().paged_prefill_attention(o1, q[s * L:(s + 1) * L].contiguous(), kc, vc, KVH, scale,
+                                      bt[s:s + 1].contiguous(), sl[:1], one_cu, L, BS)
+        assert torch.equal(o1, out[s * L:(s + 1) * L]), "batch independence"
+    half = torch.empty(512, H, D, dtype=torch.bfloat16, device=d)
+    ops().paged_prefill_attention(half, q[:512].contiguous(), kc, vc, KVH, scale, bt[:1].contiguous(),
+                                  torch.tensor([512], device=d, dtype=torch.int32),
+                                  torch.tensor([0, 512], device=d, dtype=torch.int32), 512, BS)
+    assert torch.equal(half, out[:512]), "causal prefix"
+    perm = torch.tensor([5, 2, 7, 0, 3, 6, 1, 4], device=d)
+    qp = q.view(S, L, H, D)[perm].reshape(S * L, H, D).contiguous()
+    outp = torch.empty_like(q)
+    ops().paged_prefill_attention(outp, qp, kc, vc, KVH, scale, bt[perm].contiguous(), sl, cu, L, BS)
+    assert torch.equal(outp.view(S, L, H, D), out.view(S, L, H, D)[perm]), "sequence permutation"
