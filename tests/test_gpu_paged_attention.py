@@ -193,3 +193,50 @@ def test_paged_attention_both_workgroup_sizes(num_seqs):
     assert_close_rel(_run_v1(*args, 8, 16), ref1, 1e-3, "v1", abs_floor=_tol(ref1))
     ref2 = R.paged_attention_v2(q, kc, vc, 8, scale, bt, sl, max_len, slopes)[0]
     assert_close_rel(_run_v2(*args, 8, 16)[0], ref2, 1e-3, "v2", abs_floor=_tol(ref2))
+
+
+def test_decode_attention_bench_shape_properties():
+    """BASELINE decode shape (64 sequences, context 1024..1151, 32 / 8 heads, d 128, block 16) — too
+    large for the python oracle, so size-independent properties: (a) sequences are independent (a
+    sub-batch reproduces its rows bit for bit, v1 and v2); (b) v1 and v2 agree within the 1e-3
+    budget; (c) permuting the sequences permutes the rows."""
+    torch.manual_seed(13)
+    d = dev()
+    S, H, KVH, D, BS = 64, 32, 8, 128, 16
+    seq_lens = [1024 + (i * 37) % 128 for i in range(S)]
+    max_len = max(seq_lens)
+    nblk = (max_len + BS - 1) // BS
+    nb = S * nblk
+    kc = (torch.randn(nb, KVH, D // 8, BS, 8, device=d) * 0.3).to(torch.bfloat16)
+    vc = (torch.randn(nb, KVH, D, BS, device=d) * 0.3).to(torch.bfloat16)
+    q = (torch.randn(S, H, D, device=d) * 0.5).to(torch.bfloat16)
+    bt = torch.randperm(nb, device=d).to(torch.int32).view(S, nblk)
+    sl = torch.tensor(seq_lens, device=d, dtype=torch.int32)
+    scale = D ** -0.5
+    P = (max_len + 511) // 512
+
+    def v1(qq, btt, sll):
+        o = torch.empty_like(qq)
+        ops().paged_attention_v1(o, qq, kc, vc, KVH, scale, btt, sll, BS, max_len, None, "auto")
+        return o
+
+    def v2(qq, btt, sll):
+        n = qq.shape[0]
+        o = torch.empty_like(qq)
+        es = torch.empty(n, H, P, device=d, dtype=torch.float32)
+        ml = torch.empty_like(es)
+        tmp = torch.empty(n, H, P, D, device=d, dtype=torch.bfloat16)
+        ops().paged_attention_v2(o, es, ml, tmp, qq, kc, vc, KVH, scale, btt, sll, BS, max_len, None, "auto")
+        return o
+
+    o1, o2 = v1(q, bt, sl), v2(q, bt, sl)
+    assert torch.isfinite(o1.float()).all() and torch.isfinite(o2.float()).all()
+    assert_close_rel(o1, o2.cpu(), 1e-3, "v1 vs v2", abs_floor=_tol(o2.cpu()))
+    sub = torch.tensor([3, 17, 40, 63], device=d)
+    assert torch.equal(v1(q[sub].contiguous(), bt[sub].contiguous(), sl[sub].contiguous()), o1[sub])
+    # (the v2 sub-batch launch has < 768 workgroups and therefore 8-wave workgroups, the full batch
+    #  4-wave ones: the cross-wave summation order differs, so equality is up to rounding there)
+    assert_close_rel(v2(q[sub].contiguous(), bt[sub].contiguous(), sl[sub].contiguous()), o2[sub].cpu(),
+                     1e-3, "v2 sub-batch", abs_floor=_tol(o2.cpu()))
+    perm = torch.randperm(S, device=d)
+    assert torch.equal(v1(q[perm].contiguous(), bt[perm].contiguous(), sl[perm].contiguous()), o1[perm])
