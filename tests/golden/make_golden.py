@@ -164,6 +164,20 @@ def main():
     save("merge_attn_states", prefix_output=p_out, prefix_lse=p_lse.numpy(), suffix_output=s_out,
          suffix_lse=s_lse.numpy(), output=m_out, output_lse=m_lse.numpy())
 
+    # ---- int8 W8A8 ---------------------------------------------------------------
+    g = torch.Generator().manual_seed(9)
+    x8 = (torch.randn(6, 256, generator=g) * 2).to(bf)
+    x8[0, :4] = torch.tensor([0.5, 1.5, -2.5, 0.0]).to(bf)
+    q_dyn, s_dyn = R.scaled_int8_quant(x8)
+    s_static = torch.tensor([0.043], dtype=torch.float32)
+    q_st, _ = R.scaled_int8_quant(x8, s_static)
+    w8 = torch.randint(-127, 128, (64, 256), generator=g, dtype=torch.int32).to(torch.int8)   # [N, K]
+    w_s = torch.rand(1, 64, generator=g) * 9e-3 + 1e-3
+    bias8 = (torch.randn(64, generator=g) * 0.5).to(bf)
+    save("int8_w8a8", x=x8, q_dynamic=q_dyn.numpy(), scales_dynamic=s_dyn.numpy(), scale_static=s_static.numpy(),
+         q_static=q_st.numpy(), w_nk=w8.numpy(), w_scales=w_s.numpy(), bias=bias8,
+         out=R.scaled_mm_int8(q_dyn, w8.t(), s_dyn, w_s, bf, bias8))
+
 
 if __name__ == "__main__":
     main()

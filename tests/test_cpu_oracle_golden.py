@@ -200,3 +200,19 @@ def test_golden_merge_attn_states():
                                    G.bf16(z["suffix_output"]), G.f32(z["suffix_lse"]))
     assert torch.equal(out.view(torch.int16), G.bf16(z["output"]).view(torch.int16))
     assert torch.equal(lse, G.f32(z["output_lse"]))
+
+
+def test_golden_int8_w8a8():
+    """Frozen int8 fixtures pin the oracle (tests/golden/make_golden.py int8_w8a8)."""
+    z = G.load("int8_w8a8")
+    x = G.bf16(z["x"])
+    q, s = R.scaled_int8_quant(x)
+    assert np.array_equal(q.numpy(), z["q_dynamic"]) and np.array_equal(s.numpy(), z["scales_dynamic"])
+    assert list(z["q_dynamic"][0, :4]) == [round(v) for v in (0.5 * 127 / float(x[0].float().abs().max()),
+                                                               1.5 * 127 / float(x[0].float().abs().max()),
+                                                               -2.5 * 127 / float(x[0].float().abs().max()), 0.0)]
+    qs, _ = R.scaled_int8_quant(x, G.f32(z["scale_static"]))
+    assert np.array_equal(qs.numpy(), z["q_static"])
+    w = torch.from_numpy(z["w_nk"].copy())
+    out = R.scaled_mm_int8(q, w.t(), s, G.f32(z["w_scales"]), torch.bfloat16, G.bf16(z["bias"]))
+    assert torch.equal(out.view(torch.int16), G.bf16(z["out"]).view(torch.int16))

@@ -92,3 +92,19 @@ def test_int8_pipeline_and_torch_binding():
     assert_bit_exact(out1, out2, "binding")
     ref = R.scaled_mm_int8(q.cpu(), w.cpu().t(), s.cpu(), w_s.cpu(), torch.bfloat16)
     assert_bit_exact(out1, ref, "pipeline vs oracle")
+
+
+def test_golden_int8_w8a8_gpu():
+    from tests import golden_io as G
+    z = G.load("int8_w8a8")
+    dv = dev()
+    x = G.bf16(z["x"]).to(dv)
+    q, s, _ = ops().scaled_int8_quant(x)
+    assert torch.equal(q.cpu(), torch.from_numpy(z["q_dynamic"].copy()))
+    assert torch.equal(s.cpu(), G.f32(z["scales_dynamic"]))
+    qs, _, _ = ops().scaled_int8_quant(x, G.f32(z["scale_static"]).to(dv))
+    assert torch.equal(qs.cpu(), torch.from_numpy(z["q_static"].copy()))
+    w = torch.from_numpy(z["w_nk"].copy()).to(dv)
+    out = torch.empty(6, 64, dtype=torch.bfloat16, device=dv)
+    ops().cutlass_scaled_mm(out, q, w.t(), s, G.f32(z["w_scales"]).to(dv), G.bf16(z["bias"]).to(dv))
+    assert_bit_exact(out, G.bf16(z["out"]), "golden int8 GEMM")
