@@ -348,8 +348,10 @@ int mi355x_qkv_rope_cache(void* qkv, int64_t qkv_stride, const float* slabs, int
  * out[M,N] (bf16/f16) = (a_scales . a[M,K] e4m3fn row-major) x
  *                       (b_scales . b[K,N] e4m3fn COLUMN-major, ldb = b.stride(1))
  *                       (+ bias[N]).  a_scales: 1 or M floats; b_scales: 1 or N.
- * `workspace` (float, >= m*n, may be NULL) lets the small-M kernel split K across
- * workgroups; it is zero-filled by the call.
+ * `workspace` (4-byte elements, 16-byte aligned, may be NULL): M <= 64: >= m*n lets the small-M
+ * kernel split K across workgroups (zero-filled by the call); M >= 1024: >= (roundup(m,16) +
+ * roundup(n,16)) * k bytes selects the prefill kernel (operands re-tiled into MFMA operand images,
+ * LDS-DMA ring); otherwise the direct kernels run.
  * New capability behind the reference schema cutlass_scaled_mm
  * (csrc/torch_bindings.cpp:251-256; csrc/quantization/cutlass_w8a8/
  *  scaled_mm_entry.cu:34-39,84-140), which the reference only implements for int8. */

@@ -53,8 +53,8 @@ def test_scaled_int8_quant_zero_row_and_azp():
 
 
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("m", [1, 16, 33, 64, 100, 300])
-@pytest.mark.parametrize("k,n", [(256, 128), (1024, 768), (4096, 1024)])
+@pytest.mark.parametrize("m", [1, 16, 33, 64, 100, 300, 1030])
+@pytest.mark.parametrize("k,n", [(256, 128), (1024, 768), (4096, 1024), (320, 272)])
 @pytest.mark.parametrize("per_token,per_channel,use_bias", [(False, False, False), (True, True, True),
                                                            (True, False, False), (False, True, True)])
 def test_cutlass_scaled_mm_int8(out_dtype, m, k, n, per_token, per_channel, use_bias):

@@ -686,6 +686,18 @@ def scaled_int8_quant(input: torch.Tensor, scale: Optional[torch.Tensor] = None,
     return out, scales, None
 
 
+_F32_SCRATCH = {}
+
+
+def _scratch_f32(elems: int, device) -> torch.Tensor:
+    """Per-device reusable fp32 scratch (stream-ordered use), grown on demand."""
+    t = _F32_SCRATCH.get(device)
+    if t is None or t.numel() < elems:
+        t = torch.empty(elems, dtype=torch.float32, device=device)
+        _F32_SCRATCH[device] = t
+    return t
+
+
 def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:
     """The reference returns False (scaled_mm_entry.cu:22-24); gfx950 has OCP-fp8 MFMA."""
     return True
@@ -719,7 +731,14 @@ def cutlass_scaled_mm(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
     if bias is not None and (bias.numel() != n or not bias.is_contiguous() or bias.dtype != out.dtype):
         raise RuntimeError("cutlass_scaled_mm: bad bias")
     # small-M (decode) shapes split K across workgroups through an fp32 workspace
-    ws = torch.empty((m, n), dtype=torch.float32, device=a.device) if m <= 64 else None
+    if m <= 64:
+        ws = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    elif m >= 1024 and k % 64 == 0:
+        # prefill: scratch for the re-tiled operands, (roundup(m,16) + roundup(n,16)) * k bytes
+        need = ((m + 15) // 16 * 16 + (n + 15) // 16 * 16) * k
+        ws = _scratch_f32((need + 3) // 4, a.device)
+    else:
+        ws = None
     fn = _abi.load().mi355x_scaled_mm_int8 if a.dtype == torch.int8 else _abi.load().mi355x_scaled_mm_fp8
     rc = fn(
         _ptr(out), _ptr(a), _ptr(b), _ptr(a_scales), a_scales.numel(), _ptr(b_scales),

@@ -24,7 +24,7 @@
 // through int32 atomics), epilogue out = T(a_s * (b_s * float(acc)) + bias) in fp32 — the
 // reference's int8 cutlass_scaled_mm (csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu:34-39,
 // :84-140; epilogue order as tests/kernels/utils.py baseline_scaled_mm).
-#include "common.cuh"
+#include "w4a16.cuh"   // pack_a_kernel / frag_swz: the packed operand image of the prefill path
 
 namespace mi355x {
 
@@ -310,6 +310,136 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
   }
 }
 
+// ------------------------------------------------------------------------- prefill (M >= 1024)
+// Same structure as the w4a16 prefill GEMM (w4a16_unfused.hip): both operands are first re-tiled
+// into 1-KiB operand images (pack_a_kernel on the byte matrices viewed as 2-byte elements: a
+// piece = 16 rows x 64 k-bytes, slot frag_swz(lr, lc) = row lc, bytes 16 lr .. 16 lr + 15), then a
+// 256 x 256 tile / 8-wave kernel streams pieces by LDS-DMA through a 4-stage ring; a 16-byte
+// fragment feeds two MFMAs (low / high 8 bytes — the same k permutation on both operands).
+constexpr int kP8Stages = 4;
+
+template <typename T, typename Op>
+__global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
+    T* __restrict__ out, const uint4* __restrict__ pa, const uint4* __restrict__ pb,
+    const float* __restrict__ a_scales, int a_per_row, const float* __restrict__ b_scales,
+    int b_per_col, const T* __restrict__ bias, int m, int n, int k, int64_t ldc, int num_m_blocks,
+    int num_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* lds = reinterpret_cast<uint4*>(smem);
+  constexpr int kStage = 2 * 16 * 64;  // uint4 per stage: 16 A pieces + 16 B pieces = 32 KiB
+  constexpr int kBOff = 16 * 64;
+  int tile;
+  {
+    const int b = blockIdx.x;
+    const int q = num_tiles / 8, r = num_tiles % 8;
+    const int xcd = b % 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+  }
+  int mb, nb;
+  {
+    constexpr int GM = 8;
+    const int num_n_blocks = num_tiles / num_m_blocks;
+    const int group = tile / (GM * num_n_blocks);
+    const int first_m = group * GM;
+    const int gsz = min(num_m_blocks - first_m, GM);
+    const int within = tile - group * GM * num_n_blocks;
+    mb = first_m + within % gsz;
+    nb = within / gsz;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lc = lane & 15, lr = lane >> 4;
+  const int ktiles = k / 64;   // pieces along K
+
+  const uint4* a_src[2];
+  const uint4* b_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = wave * 2 + i;
+    int gmt = mb * 16 + p;
+    const int max_mt = ((m + 15) >> 4) - 1;
+    gmt = gmt < max_mt ? gmt : max_mt;
+    a_src[i] = pa + (int64_t)gmt * ktiles * 64 + lane;
+    int gnt = nb * 16 + p;
+    const int max_nt = ((n + 15) >> 4) - 1;
+    gnt = gnt < max_nt ? gnt : max_nt;
+    b_src[i] = pb + (int64_t)gnt * ktiles * 64 + lane;
+  }
+  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
+  auto stage = [&](int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = wave * 2 + i;
+      lds_dma16(a_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + p * 64) * 16);
+      lds_dma16(b_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + kBOff + p * 64) * 16);
+    }
+  };
+  typename Op::acc_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[i][t] = typename Op::acc_t{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < kP8Stages - 1; ++s2) {
+    if (s2 < ktiles) stage(s2, s2);
+  }
+  const int frag = frag_swz(lr, lc);
+  int cur = 0;
+  for (int kt = 0; kt < ktiles; ++kt) {
+    if (kt + kP8Stages - 2 < ktiles) lds_dma_wait<4 * (kP8Stages - 2)>();
+    else lds_dma_wait<0>();
+    __syncthreads();
+    {
+      const int nxt = kt + kP8Stages - 1;
+      int slot = cur + kP8Stages - 1;
+      slot = slot >= kP8Stages ? slot - kP8Stages : slot;
+      if (nxt < ktiles) stage(slot, nxt);
+    }
+    const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
+    const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
+    uint4 bf[4], af[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bf[t] = bbuf[t * 64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t a0 = ((uint64_t)af[i].y << 32) | af[i].x;
+      const uint64_t a1 = ((uint64_t)af[i].w << 32) | af[i].z;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint64_t b0 = ((uint64_t)bf[t].y << 32) | bf[t].x;
+        const uint64_t b1 = ((uint64_t)bf[t].w << 32) | bf[t].z;
+        acc[i][t] = Op::run(a0, b0, acc[i][t]);
+        acc[i][t] = Op::run(a1, b1, acc[i][t]);
+      }
+    }
+    cur = cur + 1 == kP8Stages ? 0 : cur + 1;
+  }
+  // epilogue: tile t of a wave = 16 consecutive columns (plain packing of B), lane lc = column
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int col = nb * 256 + (wn * 4 + t) * 16 + lc;
+    if (col >= n) continue;
+    const float bs = b_scales[b_per_col ? col : 0];
+    const float bi = bias ? to_f32(bias[col]) : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = mb * 256 + wm * 128 + i * 16 + 4 * lr + j;
+        if (row < m) {
+          const float as = a_scales[a_per_row ? row : 0];
+          out[(int64_t)row * ldc + col] = out_cast<T>(Op::finish(acc[i][t][j], as, bs, bi));
+        }
+      }
+    }
+  }
+}
+
 // split-K epilogue: out = T(ws * a_s * b_s + bias)
 template <typename T, typename Op>
 __global__ void fp8_gemm_finish_kernel(T* __restrict__ out, const typename Op::elem_t* __restrict__ ws,
@@ -330,6 +460,44 @@ static int run_fp8(const Fp8Args& g) {
   const int b_per_col = g.b_scales_numel > 1;
   T* out = static_cast<T*>(g.out);
   const T* bias = static_cast<const T*>(g.bias);
+  {
+    // prefill: both operands re-tiled into operand images, then the LDS-DMA ring kernel
+    const int64_t m_pad = ((int64_t)g.m + 15) / 16 * 16, n_pad = ((int64_t)g.n + 15) / 16 * 16;
+    const int64_t need = (m_pad + n_pad) * g.k;   // bytes
+    if (g.m >= 1024 && g.ws != nullptr && g.ws_elems * 4 >= need && g.k % 64 == 0 &&
+        (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0) {
+      bf16_t* pa = reinterpret_cast<bf16_t*>(g.ws);
+      bf16_t* pb = pa + m_pad * g.k / 2;
+      const int k2 = g.k / 2;   // the byte matrices viewed as 2-byte elements
+      hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, (int)(m_pad / 16)),
+                         dim3(256), 0, g.stream, pa, reinterpret_cast<const bf16_t*>(g.a), g.m, k2,
+                         g.lda / 2);
+      hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, (int)(n_pad / 16)),
+                         dim3(256), 0, g.stream, pb, reinterpret_cast<const bf16_t*>(g.b), g.n, k2,
+                         g.ldb / 2);
+      int rc = check_launch("scaled_mm(pack)");
+      if (rc) return rc;
+      const int num_m_blocks = (g.m + 255) / 256, num_n_blocks = (g.n + 255) / 256;
+      const int num_tiles = num_m_blocks * num_n_blocks;
+      const size_t smem = (size_t)kP8Stages * 2048 * sizeof(uint4);
+      auto kern = gemm8_packed_kernel<T, Op>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) {
+          set_error("scaled_mm(packed): cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
+          return MI355X_EUNSUPPORTED;
+        }
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(512), smem, g.stream, out,
+                         reinterpret_cast<const uint4*>(pa), reinterpret_cast<const uint4*>(pb),
+                         g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.k, g.ldc,
+                         num_m_blocks, num_tiles);
+      return check_launch("scaled_mm(packed)");
+    }
+  }
   if (g.m > 64) {
     const int num_m_blocks = (g.m + kF8BM - 1) / kF8BM;
     const int num_n_blocks = (g.n + kF8BN - 1) / kF8BN;
