@@ -29,12 +29,28 @@
 namespace mi355x {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
 struct OpFp8 {
+  static constexpr bool kWide = true;    // has a 16x16x128 MFMA (run32)
   typedef f32x4_t acc_t;
   typedef float elem_t;
   static __device__ __forceinline__ acc_t run(uint64_t a, uint64_t b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)a, (long)b, c, 0, 0, 0);
+  }
+  // one 64-k piece (16 B per lane on each side): two 16x16x32 MFMAs
+  static __device__ __forceinline__ acc_t run16(uint4 a, uint4 b, acc_t c) {
+    c = run(((uint64_t)a.y << 32) | a.x, ((uint64_t)b.y << 32) | b.x, c);
+    return run(((uint64_t)a.w << 32) | a.z, ((uint64_t)b.w << 32) | b.z, c);
+  }
+  // two 64-k pieces in one 16x16x128 MFMA (gfx950 f8f6f4 form: cbsz = blgp = 0 selects e4m3 on
+  // both sides, the E8M0 block scales are 127 = 2^0)
+  static __device__ __forceinline__ acc_t run32(uint4 a0, uint4 a1, uint4 b0, uint4 b1, acc_t c) {
+    const i32x8_t a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w,
+                       (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    const i32x8_t b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w,
+                       (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 127, 0, 127);
   }
   // (a_s . A)(b_s . B) + bias, the order the fp8 oracle uses
   static __device__ __forceinline__ float finish(float acc, float as, float bs, float bi) {
@@ -42,10 +58,20 @@ struct OpFp8 {
   }
 };
 struct OpI8 {
+  static constexpr bool kWide = false;
   typedef i32x4_t acc_t;
   typedef int elem_t;
   static __device__ __forceinline__ acc_t run(uint64_t a, uint64_t b, acc_t c) {
     return __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a, (long)b, c, 0, 0, 0);
+  }
+  // one 64-k piece in one 16x16x64 MFMA
+  static __device__ __forceinline__ acc_t run16(uint4 a, uint4 b, acc_t c) {
+    const i32x4_t av = {(int)a.x, (int)a.y, (int)a.z, (int)a.w};
+    const i32x4_t bv = {(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+    return __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ acc_t run32(uint4 a0, uint4 a1, uint4 b0, uint4 b1, acc_t c) {
+    return run16(a1, b1, run16(a0, b0, c));
   }
   static __device__ __forceinline__ float finish(int acc, float as, float bs, float bi) {
 #pragma clang fp contract(off)
@@ -316,9 +342,10 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
 // piece = 16 rows x 64 k-bytes, slot frag_swz(lr, lc) = row lc, bytes 16 lr .. 16 lr + 15), then a
 // 256 x 256 tile / 8-wave kernel streams pieces by LDS-DMA through a 4-stage ring; a 16-byte
 // fragment feeds two MFMAs (low / high 8 bytes — the same k permutation on both operands).
-constexpr int kP8Stages = 4;
-
-template <typename T, typename Op>
+// P = 64-k pieces per stage and operand tile: 1 -> a 4-stage ring of 32-KiB stages, every 16-byte
+// fragment feeds Op::run16; 2 (fp8, K % 128 == 0) -> two 64-KiB stages, the fragments of two
+// adjacent pieces form the 32-byte operands of one 16x16x128 MFMA (Op::run32).
+template <typename T, typename Op, int P>
 __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
     T* __restrict__ out, const uint4* __restrict__ pa, const uint4* __restrict__ pb,
     const float* __restrict__ a_scales, int a_per_row, const float* __restrict__ b_scales,
@@ -326,7 +353,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
     int num_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
-  constexpr int kStage = 2 * 16 * 64;  // uint4 per stage: 16 A pieces + 16 B pieces = 32 KiB
+  constexpr int S = P == 1 ? 4 : 2;       // ring depth
+  constexpr int kPiece = 2 * 16 * 64;     // uint4 per 64-k slice: 16 A pieces + 16 B pieces = 32 KiB
+  constexpr int kStage = P * kPiece;
   constexpr int kBOff = 16 * 64;
   int tile;
   {
@@ -350,7 +379,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int lc = lane & 15, lr = lane >> 4;
-  const int ktiles = k / 64;   // pieces along K
+  const int kpieces = k / 64;       // pieces along K
+  const int kstages = kpieces / P;
 
   const uint4* a_src[2];
   const uint4* b_src[2];
@@ -360,19 +390,24 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
     int gmt = mb * 16 + p;
     const int max_mt = ((m + 15) >> 4) - 1;
     gmt = gmt < max_mt ? gmt : max_mt;
-    a_src[i] = pa + (int64_t)gmt * ktiles * 64 + lane;
+    a_src[i] = pa + (int64_t)gmt * kpieces * 64 + lane;
     int gnt = nb * 16 + p;
     const int max_nt = ((n + 15) >> 4) - 1;
     gnt = gnt < max_nt ? gnt : max_nt;
-    b_src[i] = pb + (int64_t)gnt * ktiles * 64 + lane;
+    b_src[i] = pb + (int64_t)gnt * kpieces * 64 + lane;
   }
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
-  auto stage = [&](int buf, int kt) {
+  auto stage = [&](int buf, int ks) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int p = wave * 2 + i;
-      lds_dma16(a_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + p * 64) * 16);
-      lds_dma16(b_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + kBOff + p * 64) * 16);
+    for (int pp = 0; pp < P; ++pp) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int p = wave * 2 + i;
+        const int64_t src = (int64_t)(ks * P + pp) * 64;
+        const int dst = buf * kStage + pp * kPiece + p * 64;
+        lds_dma16(a_src[i] + src, lds_base + dst * 16);
+        lds_dma16(b_src[i] + src, lds_base + (dst + kBOff) * 16);
+      }
     }
   };
   typename Op::acc_t acc[8][4];
@@ -382,42 +417,61 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
     for (int t = 0; t < 4; ++t) acc[i][t] = typename Op::acc_t{0, 0, 0, 0};
   }
 #pragma unroll
-  for (int s2 = 0; s2 < kP8Stages - 1; ++s2) {
-    if (s2 < ktiles) stage(s2, s2);
+  for (int s2 = 0; s2 < S - 1; ++s2) {
+    if (s2 < kstages) stage(s2, s2);
   }
   const int frag = frag_swz(lr, lc);
   int cur = 0;
-  for (int kt = 0; kt < ktiles; ++kt) {
-    if (kt + kP8Stages - 2 < ktiles) lds_dma_wait<4 * (kP8Stages - 2)>();
+  for (int ks = 0; ks < kstages; ++ks) {
+    if (ks + S - 2 < kstages) lds_dma_wait<4 * P * (S - 2)>();
     else lds_dma_wait<0>();
     __syncthreads();
     {
-      const int nxt = kt + kP8Stages - 1;
-      int slot = cur + kP8Stages - 1;
-      slot = slot >= kP8Stages ? slot - kP8Stages : slot;
-      if (nxt < ktiles) stage(slot, nxt);
+      const int nxt = ks + S - 1;
+      int slot = cur + S - 1;
+      slot = slot >= S ? slot - S : slot;
+      if (nxt < kstages) stage(slot, nxt);
     }
     const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
     const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
-    uint4 bf[4], af[8];
+    if constexpr (P == 1) {
+      uint4 bf[4], af[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bf[t] = bbuf[t * 64];
+      for (int t = 0; t < 4; ++t) bf[t] = bbuf[t * 64];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint64_t a0 = ((uint64_t)af[i].y << 32) | af[i].x;
-      const uint64_t a1 = ((uint64_t)af[i].w << 32) | af[i].z;
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = Op::run16(af[i], bf[t], acc[i][t]);
+      }
+    } else {
+      uint4 bf[4][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const uint64_t b0 = ((uint64_t)bf[t].y << 32) | bf[t].x;
-        const uint64_t b1 = ((uint64_t)bf[t].w << 32) | bf[t].z;
-        acc[i][t] = Op::run(a0, b0, acc[i][t]);
-        acc[i][t] = Op::run(a1, b1, acc[i][t]);
+        bf[t][0] = bbuf[t * 64];
+        bf[t][1] = bbuf[kPiece + t * 64];
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        uint4 af[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          af[i][0] = abuf[(4 * h + i) * 64];
+          af[i][1] = abuf[kPiece + (4 * h + i) * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[4 * h + i][t] =
+                Op::run32(af[i][0], af[i][1], bf[t][0], bf[t][1], acc[4 * h + i][t]);
+          }
+        }
       }
     }
-    cur = cur + 1 == kP8Stages ? 0 : cur + 1;
+    cur = cur + 1 == S ? 0 : cur + 1;
   }
   // epilogue: tile t of a wave = 16 consecutive columns (plain packing of B), lane lc = column
 #pragma unroll
@@ -479,22 +533,32 @@ static int run_fp8(const Fp8Args& g) {
       if (rc) return rc;
       const int num_m_blocks = (g.m + 255) / 256, num_n_blocks = (g.n + 255) / 256;
       const int num_tiles = num_m_blocks * num_n_blocks;
-      const size_t smem = (size_t)kP8Stages * 2048 * sizeof(uint4);
-      auto kern = gemm8_packed_kernel<T, Op>;
-      static bool attr_set = false;
-      if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) {
-          set_error("scaled_mm(packed): cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
-          return MI355X_EUNSUPPORTED;
+      const size_t smem = (size_t)4 * 2048 * sizeof(uint4);   // 128 KiB in either ring shape
+      auto launch = [&](auto kern, bool& attr_set) -> int {
+        if (!attr_set) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+          if (e != hipSuccess) {
+            set_error("scaled_mm(packed): cannot reserve %zu B of LDS: %s", smem,
+                      hipGetErrorString(e));
+            return MI355X_EUNSUPPORTED;
+          }
+          attr_set = true;
         }
-        attr_set = true;
+        hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(512), smem, g.stream, out,
+                           reinterpret_cast<const uint4*>(pa), reinterpret_cast<const uint4*>(pb),
+                           g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.k, g.ldc,
+                           num_m_blocks, num_tiles);
+        return 0;
+      };
+      static bool attr1 = false, attr2 = false;
+      bool wide = false;
+      if constexpr (Op::kWide) wide = g.k % 128 == 0;
+      if constexpr (Op::kWide) {
+        if (wide) rc = launch(gemm8_packed_kernel<T, Op, 2>, attr2);
       }
-      hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(512), smem, g.stream, out,
-                         reinterpret_cast<const uint4*>(pa), reinterpret_cast<const uint4*>(pb),
-                         g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.k, g.ldc,
-                         num_m_blocks, num_tiles);
+      if (!wide) rc = launch(gemm8_packed_kernel<T, Op, 1>, attr1);
+      if (rc) return rc;
       return check_launch("scaled_mm(packed)");
     }
   }
