@@ -44,7 +44,9 @@ def _mk(m, n, k, per_token, per_channel, bias, out_dtype, seed=0):
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,n,k", [(1, 256, 128), (16, 128, 512), (33, 496, 1024), (64, 1280, 8192),
                                    (100, 256, 256), (512, 512, 512), (300, 1008, 1024),
-                                   (1030, 272, 320), (2048, 512, 1024)])   # last two: prefill kernel
+                                   # prefill kernel: {16x16x32, 16x16x128 MFMA} x {plain, interleaved B}
+                                   (1030, 272, 320), (2048, 512, 1024), (1100, 320, 192),
+                                   (1030, 272, 384)])
 @pytest.mark.parametrize("per_token,per_channel", [(False, False), (True, True), (True, False), (False, True)])
 @pytest.mark.parametrize("bias", [False, True])
 def test_scaled_mm_fp8(out_dtype, m, n, k, per_token, per_channel, bias):

@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
 // P = 64-k pieces per stage and operand tile: 1 -> a 4-stage ring of 32-KiB stages, every 16-byte
 // fragment feeds Op::run16; 2 (fp8, K % 128 == 0) -> two 64-KiB stages, the fragments of two
 // adjacent pieces form the 32-byte operands of one 16x16x128 MFMA (Op::run32).
-template <typename T, typename Op, int P>
+// IL: B was packed with interleaved rows (n % 64 == 0): a lane owns 4 adjacent output columns and
+// stores them as one 8-byte word; otherwise lane lc = one column per 16-column tile.
+template <typename T, typename Op, int P, bool IL>
 __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
     T* __restrict__ out, const uint4* __restrict__ pa, const uint4* __restrict__ pb,
     const float* __restrict__ a_scales, int a_per_row, const float* __restrict__ b_scales,
@@ -473,6 +475,32 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
     }
     cur = cur + 1 == S ? 0 : cur + 1;
   }
+  if constexpr (IL) {
+    const int col = nb * 256 + wn * 64 + 4 * lc;
+    if (col >= n) return;
+    float bs[4], bi[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      bs[t] = b_scales[b_per_col ? col + t : 0];
+      bi[t] = bias ? to_f32(bias[col + t]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = mb * 256 + wm * 128 + i * 16 + 4 * lr + j;
+        if (row < m) {
+          const float as = a_scales[a_per_row ? row : 0];
+          T o[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) o[t] = out_cast<T>(Op::finish(acc[i][t][j], as, bs[t], bi[t]));
+          *reinterpret_cast<uint2*>(out + (int64_t)row * ldc + col) =
+              *reinterpret_cast<const uint2*>(o);
+        }
+      }
+    }
+    return;
+  }
   // epilogue: tile t of a wave = 16 consecutive columns (plain packing of B), lane lc = column
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -522,13 +550,15 @@ static int run_fp8(const Fp8Args& g) {
         (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0) {
       bf16_t* pa = reinterpret_cast<bf16_t*>(g.ws);
       bf16_t* pb = pa + m_pad * g.k / 2;
+      // 4 adjacent output columns per lane (8-byte stores) when the shape allows it
+      const bool il = g.n % 64 == 0 && g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
       const int k2 = g.k / 2;   // the byte matrices viewed as 2-byte elements
       hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, (int)(m_pad / 16)),
                          dim3(256), 0, g.stream, pa, reinterpret_cast<const bf16_t*>(g.a), g.m, k2,
                          g.lda / 2);
       hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, (int)(n_pad / 16)),
                          dim3(256), 0, g.stream, pb, reinterpret_cast<const bf16_t*>(g.b), g.n, k2,
-                         g.ldb / 2);
+                         g.ldb / 2, il ? 1 : 0);
       int rc = check_launch("scaled_mm(pack)");
       if (rc) return rc;
       const int num_m_blocks = (g.m + 255) / 256, num_n_blocks = (g.n + 255) / 256;
@@ -551,13 +581,19 @@ static int run_fp8(const Fp8Args& g) {
                            num_m_blocks, num_tiles);
         return 0;
       };
-      static bool attr1 = false, attr2 = false;
+      static bool attr[4] = {false, false, false, false};
       bool wide = false;
       if constexpr (Op::kWide) wide = g.k % 128 == 0;
       if constexpr (Op::kWide) {
-        if (wide) rc = launch(gemm8_packed_kernel<T, Op, 2>, attr2);
+        if (wide) {
+          rc = il ? launch(gemm8_packed_kernel<T, Op, 2, true>, attr[3])
+                  : launch(gemm8_packed_kernel<T, Op, 2, false>, attr[2]);
+        }
       }
-      if (!wide) rc = launch(gemm8_packed_kernel<T, Op, 1>, attr1);
+      if (!wide) {
+        rc = il ? launch(gemm8_packed_kernel<T, Op, 1, true>, attr[1])
+                : launch(gemm8_packed_kernel<T, Op, 1, false>, attr[0]);
+      }
       if (rc) return rc;
       return check_launch("scaled_mm(packed)");
     }

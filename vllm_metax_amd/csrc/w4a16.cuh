@@ -114,10 +114,13 @@ __device__ __forceinline__ int frag_swz(int lr, int lc) {
 // (slot swz(lr, lc) = A[16 mt + lc][32 kt + 8 lr .. +7]); rows >= M are zero.  One workgroup
 // packs 16 rows x kPackK k: coalesced 16-B reads (a row's 2 KiB by 128 lanes), all 8 loads of a
 // thread in flight before the shuffle in LDS, the 32 KiB image is written out linearly.
+// interleave != 0: piece 4 G + t holds rows 64 G + 4 r + t (r = 0..15) instead of 16 consecutive
+// rows, so that a lane of the consuming GEMM ends up with 4 adjacent outputs along this axis.
 constexpr int kPackK = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void pack_a_kernel(T* __restrict__ packed, const T* __restrict__ a,
-                                                     int m, int k, int64_t lda) {
+                                                     int m, int k, int64_t lda,
+                                                     int interleave = 0) {
   __shared__ uint4 img[(kPackK / 32) * 64];        // 32 pieces of 1 KiB
   const int mt = blockIdx.y;
   const int k0 = blockIdx.x * kPackK;              // first k of this block
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void pack_a_kernel(T* __restrict__ packed, con
   for (int i = 0; i < kIters; ++i) {
     const int idx = threadIdx.x + i * 256;         // row = idx / 128, chunk = idx % 128
     const int r = idx / kChunksPerRow, ch = idx % kChunksPerRow;
-    const int row = mt * 16 + r;
+    const int row = interleave ? (mt >> 2) * 64 + 4 * r + (mt & 3) : mt * 16 + r;
     const int kk = k0 + ch * 8;
     v[i] = make_uint4(0, 0, 0, 0);
     if (row < m && kk < k) v[i] = *reinterpret_cast<const uint4*>(a + (int64_t)row * lda + kk);
