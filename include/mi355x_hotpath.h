@@ -220,6 +220,13 @@ int mi355x_rotary_embedding(const int64_t* positions, void* query, void* key,
 int mi355x_silu_and_mul(void* out, const void* input, int num_tokens, int d, int dtype,
                         mi355x_stream stream);
 
+/* out (fp8 e4m3, [tokens, d]) = fp8_sat(T(silu(x) * y) * (1 / *scale)): the gated activation with
+ * the static per-tensor fp8 quantisation of the following FP8 GEMM fused in. input fp16 / bf16.
+ * ref: csrc/quantization/activation_kernels.cu:21-90 (kernel), :117-127 (host),
+ * schema csrc/torch_bindings.cpp:115-117. */
+int mi355x_silu_and_mul_quant(void* out, const void* input, const float* scale, int num_tokens,
+                              int d, int dtype, mi355x_stream stream);
+
 /* ------------------------------------------------------- int4 weight-only --
  * awq_to_gptq_4bit: AWQ qweight [K, N/8] (N-interleaved nibbles) -> exllama
  * layout, memory [K/8, N] words, nibble p of word (kk,n) = W[8kk + {0,2,4,6,1,3,5,7}[p], n].

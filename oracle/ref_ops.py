@@ -328,6 +328,14 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     return (s.float() * b.float()).to(x.dtype)
 
 
+def silu_and_mul_quant(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """csrc/quantization/activation_kernels.cu:21-90: the T-rounded silu(x) * y (as silu_and_mul),
+    times inverted_scale = 1 / *scale (:57), clamped to +-448 and cast RNE to e4m3
+    (scaled_fp8_conversion<true>, csrc/quantization/fp8/common.cuh:25-38)."""
+    inv = np.float32(1.0) / np.float32(scale.float().item())
+    return _to_fp8_sat(silu_and_mul(x).float() * inv)
+
+
 # ================================================================ merge_attn_states
 def merge_attn_states(prefix_output: torch.Tensor, prefix_lse: torch.Tensor,
                       suffix_output: torch.Tensor, suffix_lse: torch.Tensor):

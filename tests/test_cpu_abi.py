@@ -79,7 +79,7 @@ def test_torch_bindings_register_reference_op_names(built):
                  "awq_dequantize", "awq_to_gptq_4bit", "gptq_gemm", "gptq_shuffle",
                  "cutlass_scaled_mm", "cutlass_scaled_mm_supports_fp8", "static_scaled_fp8_quant",
                  "dynamic_scaled_fp8_quant", "dynamic_per_token_scaled_fp8_quant", "silu_and_mul",
-                 "weak_ref_tensor"]:
+                 "silu_and_mul_quant", "weak_ref_tensor"]:
         assert hasattr(torch.ops._C, name), name
     for name in ["reshape_and_cache", "reshape_and_cache_flash", "copy_blocks", "swap_blocks"]:
         assert hasattr(torch.ops._C_cache_ops, name), name

@@ -15,6 +15,7 @@ Tolerances (stated per SURVEY §8 / north_star):
   * rotary / silu: bit-exact for 16-bit types (pure per-element arithmetic with the
     same rounding points); fp32 within 1e-6 relative (fma contraction).
 """
+import numpy as np
 import pytest
 import torch
 
@@ -383,3 +384,39 @@ def test_qkv_rope_cache_matches_the_three_ops(dtype, sk, H, KVH, D):
     assert_bit_exact(qkv_d[:, H * D:(H + KVH) * D].contiguous(), ref_k.contiguous(), "k")
     assert_bit_exact(kc_d, ref_kc, "key_cache")
     assert_bit_exact(vc_d, ref_vc, "value_cache")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d_", [13, 512, 14336])
+@pytest.mark.parametrize("tokens", [1, 83, 70000])
+def test_silu_and_mul_quant(dtype, d_, tokens):
+    """fp8(silu_and_mul(x) / scale), ref csrc/quantization/activation_kernels.cu:21-127.  Parity
+    unpinned beyond the oracle: the reference holds no vectors for this op."""
+    if tokens == 70000 and d_ != 13:
+        pytest.skip("the > 65535-token case is covered at the small width")
+    torch.manual_seed(1)
+    x = (torch.randn(tokens, 2 * d_) * 3).to(dtype)
+    scale = torch.tensor([0.037])
+    d = dev()
+    xd = x.to(d)
+    out = torch.empty(tokens, d_, dtype=torch.float8_e4m3fn, device=d)
+    ops().silu_and_mul_quant(out, xd, scale.to(d))
+    # the quantisation step itself is exact given the device's own T-rounded product (whose expf
+    # may differ from torch.exp by an ulp, see test_silu_and_mul)
+    mid = torch.empty(tokens, d_, dtype=dtype, device=d)
+    ops().silu_and_mul(mid, xd)
+    inv = np.float32(1.0) / np.float32(0.037)
+    want = (mid.float().cpu() * inv).clamp(-448, 448).to(torch.float8_e4m3fn)
+    assert torch.equal(out.cpu().view(torch.uint8), want.view(torch.uint8))
+    ref = R.silu_and_mul_quant(x, scale)
+    diff = (out.cpu().view(torch.uint8) != ref.view(torch.uint8)).float().mean().item()
+    assert diff < 2e-3, f"silu_and_mul_quant differs from the oracle in {diff:.2%} of the bytes"
+    # saturation: a scale small enough to overflow clamps to +-448
+    tiny = torch.tensor([1e-6], device=d)
+    ops().silu_and_mul_quant(out, xd, tiny)
+    assert out.float().abs().max().item() <= 448.0 and not torch.isnan(out.float()).any()
+    # and through the registered op
+    import vllm_metax_amd._C  # noqa: F401
+    out2 = torch.empty_like(out)
+    torch.ops._C.silu_and_mul_quant(out2, xd, tiny)
+    assert torch.equal(out.view(torch.uint8), out2.view(torch.uint8))

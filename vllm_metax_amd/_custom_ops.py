@@ -427,6 +427,27 @@ def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
     _abi.check(rc, "silu_and_mul")
 
 
+def silu_and_mul_quant(out: torch.Tensor, input: torch.Tensor, scale: torch.Tensor) -> None:
+    """torch.ops._C.silu_and_mul_quant (csrc/quantization/activation_kernels.cu:117-127): out is
+    fp8 e4m3 [..., d], input fp16 / bf16 [..., 2 d], scale one fp32 element."""
+    _dev(out, input, scale)
+    if out.dtype != torch.float8_e4m3fn:
+        raise RuntimeError("silu_and_mul_quant: out must be torch.float8_e4m3fn")
+    if input.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("silu_and_mul_quant: input must be float16 or bfloat16")
+    if input.size(-1) % 2 != 0:
+        raise RuntimeError("silu_and_mul_quant: last dimension of input must be even")
+    if scale.dtype != torch.float32 or scale.numel() != 1:
+        raise RuntimeError("silu_and_mul_quant: scale must be one float32 element")
+    if not (out.is_contiguous() and input.is_contiguous()):
+        raise RuntimeError("silu_and_mul_quant: tensors must be contiguous")
+    d = input.size(-1) // 2
+    num_tokens = input.numel() // input.size(-1) if d else 0
+    rc = _abi.load().mi355x_silu_and_mul_quant(_ptr(out), _ptr(input), _ptr(scale), num_tokens, d,
+                                               _dt(input), _stream())
+    _abi.check(rc, "silu_and_mul_quant")
+
+
 # ----------------------------------------------------------------- int4 weight-only
 _DQ_SCRATCH: dict = {}
 

@@ -131,6 +131,22 @@ void silu_and_mul(Tensor& out, Tensor& input) {
      "silu_and_mul");
 }
 
+// ref: csrc/quantization/activation_kernels.cu:117-127
+void silu_and_mul_quant(Tensor& out, Tensor& input, Tensor& scale) {
+  TORCH_CHECK(out.dtype() == at::kFloat8_e4m3fn, "silu_and_mul_quant: out must be float8_e4m3fn");
+  TORCH_CHECK(input.dtype() == at::kHalf || input.dtype() == at::kBFloat16);
+  TORCH_CHECK(input.size(-1) % 2 == 0);
+  TORCH_CHECK(scale.dtype() == at::kFloat && scale.numel() == 1);
+  TORCH_CHECK(out.is_contiguous() && input.is_contiguous());
+  const int64_t d = input.size(-1) / 2;
+  const int64_t tokens = d ? input.numel() / input.size(-1) : 0;
+  Guard g(input);
+  ok(mi355x_silu_and_mul_quant(out.data_ptr(), input.data_ptr(),
+                               static_cast<const float*>(scale.data_ptr()), tokens, d, dt(input),
+                               stream_of(input)),
+     "silu_and_mul_quant");
+}
+
 // ------------------------------------------------------------------- layernorm
 inline int64_t row_stride(const Tensor& t) { return t.dim() >= 2 ? t.stride(-2) : t.size(-1); }
 inline int64_t rows(const Tensor& t) { return t.size(-1) ? t.numel() / t.size(-1) : 0; }
@@ -572,6 +588,8 @@ TORCH_LIBRARY(_C, ops) {
 
   ops.def("silu_and_mul(Tensor! result, Tensor input) -> ()");
   ops.impl("silu_and_mul", c10::kCUDA, &silu_and_mul);
+  ops.def("silu_and_mul_quant(Tensor! result, Tensor input, Tensor scale) -> ()");
+  ops.impl("silu_and_mul_quant", c10::kCUDA, &silu_and_mul_quant);
 
   ops.def("rms_norm(Tensor! result, Tensor input, Tensor weight, float epsilon) -> ()");
   ops.impl("rms_norm", c10::kCUDA, &rms_norm);
