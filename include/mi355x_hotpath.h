@@ -281,6 +281,24 @@ int mi355x_awq_gemm_silu_mul(void* out, const void* a, const uint32_t* qweight, 
                              int m, int n, int k, int group_size, int64_t lda, int dtype,
                              mi355x_stream stream);
 
+/* The same fusion for prefill with the re-tiling of the NEXT GEMM's activations folded in
+ * (m >= 1024 only): out_packed receives act = silu_and_mul(awq_gemm(a, W_gate_up)) [m, n/2] not
+ * row-major but as the MFMA operand image the prefill GEMM reads its activations from
+ * (roundup(m,16) * n/2 elements: [row tile of 16][k tile of 32][64 slots of 16 B], slot
+ * 16 lr + (lc ^ {0,12,2,14}[lr]) = act[16 mt + lc][32 kt + 8 lr .. + 7], rows >= m zero), and
+ * mi355x_awq_gemm_packed_a consumes such an image as its `a` (then k = n/2 of the producer).
+ * Together they are bit-identical to awq_gemm(silu_and_mul(awq_gemm(a, W_gate_up)), W_down)
+ * (ref call sites: vllm_metax/quant_config/awq.py:140-147 twice around
+ * csrc/activation_kernels.cu:24-36) with one launch and one read + write of act less. */
+int mi355x_awq_gemm_silu_mul_packed(void* out_packed, const void* a, const uint32_t* qweight,
+                                    const void* scales, const uint32_t* qzeros, void* dq_workspace,
+                                    int64_t dq_workspace_bytes, int m, int n, int k, int group_size,
+                                    int64_t lda, int dtype, mi355x_stream stream);
+int mi355x_awq_gemm_packed_a(void* out, const void* a_packed, const uint32_t* qweight,
+                             const void* scales, const uint32_t* qzeros, void* dq_workspace,
+                             int64_t dq_workspace_bytes, int m, int n, int k, int group_size,
+                             int dtype, mi355x_stream stream);
+
 /* gptq_shuffle: in-place exllama nibble shuffle of q_weight [K/8, N]; with q_perm
  * (int32 [K]) rows are first made sequential through `scratch` (>= K/8*N words).
  * ref: csrc/quantization/gptq/q_gemm.cu:2415-2423, :2321-2368, qdq_4.cuh:16-29,

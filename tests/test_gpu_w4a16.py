@@ -255,3 +255,43 @@ def test_gate_up_gemm_with_fused_silu_is_bit_identical(dtype, m, k, n):
     assert out is not None
     assert_bit_exact(out, ref, "fused silu epilogue")
     assert ops().awq_gemm_silu_mul(x[:1].expand(300, k).contiguous(), q2d, qz, sc) is None   # 64 < M < 1024
+
+
+def _unpack_operand(p, m, k):
+    """Row-major [m, k] view of an operand image (include/mi355x_hotpath.h,
+    mi355x_awq_gemm_silu_mul_packed): [row tile][k tile][64 slots of 8 elements]."""
+    m_pad = (m + 15) // 16 * 16
+    img = p.data.view(m_pad // 16, k // 32, 64, 8).cpu()
+    out = torch.empty(m_pad, k, dtype=img.dtype)
+    swz = [0, 12, 2, 14]
+    for lr in range(4):
+        for lc in range(16):
+            slot = 16 * lr + (lc ^ swz[lr])
+            # rows 16 mt + lc, columns 32 kt + 8 lr .. + 7
+            out.view(m_pad // 16, 16, k // 32, 32)[:, lc, :, 8 * lr:8 * lr + 8] = img[:, :, slot, :]
+    return out
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,ffn,n2", [(1030, 256, 384, 192), (2048, 512, 1024, 512), (1300, 128, 128, 64)])
+def test_gate_up_silu_into_packed_operand_then_down_is_bit_identical(dtype, m, k, ffn, n2):
+    """MI355X-side prefill fusion pair: awq_gemm_silu_mul_packed writes act as the operand image
+    that awq_gemm_packed_a reads; image == silu_and_mul(awq_gemm) re-tiled (rows >= m zero), and
+    down(image) == awq_gemm(act) bit for bit (ragged M, several row / column blocks)."""
+    n = 2 * ffn
+    qw, qz, sc, _, _ = make_awq(k, n, 128, dtype, seed=41)
+    qw2, qz2, sc2, _, _ = make_awq(ffn, n2, 128, dtype, seed=42)
+    d = dev()
+    q2d, qz, sc = ops().awq_to_gptq_4bit(qw.to(d)), qz.to(d), sc.to(d)
+    q2d2, qz2, sc2 = ops().awq_to_gptq_4bit(qw2.to(d)), qz2.to(d), sc2.to(d)
+    x = (torch.randn(m, k, generator=torch.Generator().manual_seed(43)) * 0.5).to(dtype).to(d)
+    act = ops().awq_gemm_silu_mul(x, q2d, qz, sc)
+    ref = ops().awq_gemm(act, q2d2, qz2, sc2, 8, torch.empty(0), dtype == torch.bfloat16)
+    packed = ops().awq_gemm_silu_mul_packed(x, q2d, qz, sc)
+    assert packed is not None and packed.shape == (m, ffn)
+    img = _unpack_operand(packed, m, ffn)
+    assert_bit_exact(img[:m], act, "packed act image")
+    assert not img[m:].view(torch.int16).any(), "rows >= m of the image must be zero"
+    out = ops().awq_gemm_packed_a(packed, q2d2, qz2, sc2)
+    assert_bit_exact(out, ref, "down_proj from the packed image")
+    assert ops().awq_gemm_silu_mul_packed(x[:512], q2d, qz, sc) is None     # M < 1024

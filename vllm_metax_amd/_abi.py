@@ -60,6 +60,9 @@ PROTOTYPES = {
     "mi355x_awq_gemm_deferred": (
         _I, [_P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _L, _I, _P, _P]),
     "mi355x_awq_gemm_silu_mul": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _P]),
+    "mi355x_awq_gemm_silu_mul_packed": (
+        _I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _L, _I, _P]),
+    "mi355x_awq_gemm_packed_a": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "mi355x_gptq_shuffle": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mi355x_gptq_gemm": (
         _I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P]),

@@ -602,6 +602,70 @@ def awq_gemm_silu_mul(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.
     return out
 
 
+class PackedOperand:
+    """An activation matrix [m, k] held as the MFMA operand image the prefill GEMM reads (see
+    mi355x_awq_gemm_silu_mul_packed in include/mi355x_hotpath.h): produced by
+    awq_gemm_silu_mul_packed, consumed by awq_gemm_packed_a."""
+
+    def __init__(self, data: torch.Tensor, m: int, k: int):
+        self.data, self.m, self.k = data, m, k
+
+    @property
+    def shape(self):
+        return (self.m, self.k)
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def device(self):
+        return self.data.device
+
+
+def awq_gemm_silu_mul_packed(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
+                             scales: torch.Tensor) -> Optional[PackedOperand]:
+    """Prefill (M >= 1024) gate_up GEMM + silu_and_mul whose result is written directly as the
+    operand image of the following down_proj GEMM (no row-major act, no re-tiling launch).
+    Returns None when the path does not apply; awq_gemm_packed_a(result, ...) consumes it."""
+    _dev(input, qweight, qzeros, scales)
+    if input.dim() != 2 or input.stride(1) != 1:
+        raise RuntimeError("awq_gemm_silu_mul_packed: input must be [M, K] with unit inner stride")
+    m, k = input.shape
+    n = qweight.size(0)
+    if input.dtype not in (torch.bfloat16, torch.float16) or m < 1024 or n % 256 != 0 or k % 32 != 0:
+        return None
+    group = k // scales.size(0)
+    dq = _dq_scratch(m, n, k, input.device)
+    m_pad = (m + 15) // 16 * 16
+    out = torch.empty(m_pad * (n // 2), dtype=input.dtype, device=input.device)
+    rc = _abi.load().mi355x_awq_gemm_silu_mul_packed(
+        _ptr(out), _ptr(input), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(dq), dq.numel(),
+        m, n, k, group, input.stride(0), _dt(input), _stream())
+    _abi.check(rc, "awq_gemm_silu_mul_packed")
+    return PackedOperand(out, m, n // 2)
+
+
+def awq_gemm_packed_a(a: PackedOperand, qweight: torch.Tensor, qzeros: torch.Tensor,
+                      scales: torch.Tensor) -> torch.Tensor:
+    """awq_gemm whose activations already are an operand image (M >= 1024)."""
+    _dev(a.data, qweight, qzeros, scales)
+    m, k = a.m, a.k
+    n = qweight.size(0)
+    if qweight.size(1) * 8 != k:
+        raise RuntimeError(f"awq_gemm_packed_a: operand has k = {k}, weights have k = {qweight.size(1) * 8}")
+    group = k // scales.size(0)
+    dq = _dq_scratch(m, n, k, a.data.device)
+    if dq is None:
+        raise RuntimeError("awq_gemm_packed_a: needs M >= 1024")
+    out = torch.empty((m, n), dtype=a.data.dtype, device=a.data.device)
+    rc = _abi.load().mi355x_awq_gemm_packed_a(
+        _ptr(out), _ptr(a.data), _ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(dq), dq.numel(),
+        m, n, k, group, _dt(a.data), _stream())
+    _abi.check(rc, "awq_gemm_packed_a")
+    return out
+
+
 def awq_gemm_deferred(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
                       scales: torch.Tensor, temp_space: torch.Tensor):
     """awq_gemm that may leave its split-K reduction to the consumer: returns (out, sk).  sk >= 2:

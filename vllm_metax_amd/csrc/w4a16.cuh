@@ -184,6 +184,8 @@ struct GemmArgs {
   hipStream_t stream;
   int* defer_sk = nullptr;   // non-null: leave split-K slabs unreduced, report their count here
   bool fuse_silu = false;    // prefill gate_up: write silu_and_mul(C) [m, n/2] instead of C
+  bool out_packed = false;   // with fuse_silu, m >= 1024: write it as the operand image of the next GEMM
+  bool a_packed = false;     // m >= 1024: `a` already is an operand image (pack_a_kernel's format)
 };
 
 

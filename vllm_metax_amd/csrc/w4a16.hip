@@ -551,6 +551,43 @@ int mi355x_awq_gemm_silu_mul(void* out, const void* a, const uint32_t* qweight, 
   return rc;
 }
 
+int mi355x_awq_gemm_silu_mul_packed(void* out_packed, const void* a, const uint32_t* qweight,
+                                    const void* scales, const uint32_t* qzeros, void* dq_workspace,
+                                    int64_t dq_workspace_bytes, int m, int n, int k, int group_size,
+                                    int64_t lda, int dtype, mi355x_stream stream) {
+  GemmArgs g{out_packed, a, qweight, scales, qzeros, nullptr, 0, dq_workspace, dq_workspace_bytes,
+             m, n, k, group_size, lda, kZeroAwq, static_cast<hipStream_t>(stream)};
+  g.fuse_silu = true;
+  g.out_packed = true;
+  int rc = validate_gemm(g, "awq_gemm_silu_mul_packed");
+  if (rc || m == 0) return rc;
+  MI355X_REQUIRE((reinterpret_cast<uintptr_t>(out_packed) & 15) == 0, MI355X_EUNSUPPORTED,
+                 "awq_gemm_silu_mul_packed: out_packed must be 16-byte aligned");
+  rc = w4a16_gemm_unfused_dispatch(g, dtype);
+  MI355X_REQUIRE(rc != 1, MI355X_EUNSUPPORTED,
+                 "awq_gemm_silu_mul_packed: needs a 2-byte dtype, m >= 1024, n %% 256 == 0, k %% 32 == 0 "
+                 "and dq_workspace >= (n + roundup(m,16))*k*2 bytes; got m=%d n=%d k=%d, %lld bytes",
+                 m, n, k, (long long)dq_workspace_bytes);
+  return rc;
+}
+
+int mi355x_awq_gemm_packed_a(void* out, const void* a_packed, const uint32_t* qweight,
+                             const void* scales, const uint32_t* qzeros, void* dq_workspace,
+                             int64_t dq_workspace_bytes, int m, int n, int k, int group_size,
+                             int dtype, mi355x_stream stream) {
+  GemmArgs g{out, a_packed, qweight, scales, qzeros, nullptr, 0, dq_workspace, dq_workspace_bytes,
+             m, n, k, group_size, k, kZeroAwq, static_cast<hipStream_t>(stream)};
+  g.a_packed = true;
+  int rc = validate_gemm(g, "awq_gemm_packed_a");
+  if (rc || m == 0) return rc;
+  rc = w4a16_gemm_unfused_dispatch(g, dtype);
+  MI355X_REQUIRE(rc != 1, MI355X_EUNSUPPORTED,
+                 "awq_gemm_packed_a: needs a 2-byte dtype, m >= 1024, n %% 64 == 0, k %% 32 == 0 and "
+                 "dq_workspace >= (n + roundup(m,16))*k*2 bytes; got m=%d n=%d k=%d, %lld bytes",
+                 m, n, k, (long long)dq_workspace_bytes);
+  return rc;
+}
+
 int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,
                      const uint32_t* qzeros, const void* scales, const int* g_idx,
                      void* perm_space, float* workspace, int64_t workspace_elems,

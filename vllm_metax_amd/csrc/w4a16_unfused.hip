@@ -79,7 +79,11 @@ constexpr int kUfThreads = 512;
 // writes act[M, ffn] = silu_and_mul(C) instead of C (csrc/activation_kernels.cu:14-36): a tile is
 // then 128 gate columns + the 128 matching up columns, and every wave owns 2 gate column tiles
 // and the 2 matching up column tiles, so gate and up of one output element sit in ONE lane.
-template <typename T, bool SILU>
+// MODE: 0 = plain C; 1 = SILU epilogue, act row-major; 2 = SILU epilogue, act written as the packed
+// operand image of the NEXT GEMM (down_proj): the tile's 256 x 128 results are exchanged through
+// LDS so that every wave stores whole 1-KiB pieces, and the activation re-tiling launch of the next
+// GEMM (a read + write of the largest activation of the layer) disappears.
+template <typename T, int MODE>
 __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     T* __restrict__ c, const uint4* __restrict__ pa, const uint4* __restrict__ pb, int m, int n,
     int k, int num_m_blocks, int num_tiles) {
@@ -114,6 +118,7 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     nb = within / gsz;
   }
 
+  constexpr bool SILU = MODE != 0;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2;   // 0..1 : rows wm*128 ..
@@ -198,7 +203,41 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   }
 
   // ---- epilogue: lane holds 4 consecutive columns per (i, j) --------------------------------
-  if constexpr (SILU) {
+  if constexpr (MODE == 2) {
+    // (n % 256 == 0: every tile is 128 whole act columns; rows >= m of the last row tile are zero
+    // in the packed A, so their results are silu(0) * 0 = 0, as pack_a_kernel would write them)
+    __syncthreads();            // every wave is done with the ring: reuse it as the exchange buffer
+    const int cl = 64 * (wn >> 1) + 4 * lc + 2 * (wn & 1);     // first of this lane's 2 act columns
+    const int chunk = (cl & 31) >> 3;                          // 16-B slot column inside the piece
+    char* ex = smem + (cl >> 5) * 1024 + chunk * 256 + (cl & 7) * 2;
+    const int swz_g = ((chunk & 1) * 12) | (chunk & 2);        // frag_swz's row xor
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rowl = wm * 128 + i * 16 + 4 * lr + j;
+        const T g0 = from_f32<T>(acc[i][0][j]), g1 = from_f32<T>(acc[i][1][j]);
+        const T u0 = from_f32<T>(acc[i][2][j]), u1 = from_f32<T>(acc[i][3][j]);
+        T o[2] = {mul_t<T>(silu_t<T>(g0), u0), mul_t<T>(silu_t<T>(g1), u1)};
+        // piece (rowl / 16) * 4 + cl / 32, slot frag_swz(chunk, rowl % 16)
+        *reinterpret_cast<uint32_t*>(ex + (rowl >> 4) * 4096 + (((rowl & 15) ^ swz_g) << 4)) =
+            *reinterpret_cast<const uint32_t*>(o);
+      }
+    }
+    __syncthreads();
+    const int kt_out = n >> 6;                      // 32-k pieces per row tile of act [m, n / 2]
+    const int m_tiles = (m + 15) >> 4;
+    uint4* dst = reinterpret_cast<uint4*>(c);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int piece = wave * 8 + q;
+      const int gmt = mb * 16 + (piece >> 2);
+      const int gkt = nb * 4 + (piece & 3);
+      if (gmt < m_tiles) dst[((int64_t)gmt * kt_out + gkt) * 64 + lane] = lds[piece * 64 + lane];
+    }
+    return;
+  }
+  if constexpr (MODE == 1) {
     // tiles t = 0,1: gate columns col, col+1; t = 2,3: the same columns of the up half
     const int half = n >> 1;
     const int col = nb * 128 + 64 * (wn >> 1) + 4 * lc + 2 * (wn & 1);
@@ -240,10 +279,11 @@ static inline int64_t unfused_scratch_bytes(int m, int n, int k) {
   return ((int64_t)n + m_pad) * k * 2;
 }
 
-template <typename T, bool SILU>
+template <typename T, int MODE>
 static int run_unfused(const GemmArgs& g) {
+  constexpr bool SILU = MODE != 0;
   T* packed_b = static_cast<T*>(g.dq_ws);
-  T* packed_a = packed_b + (int64_t)g.n * g.k;
+  const T* packed_a = packed_b + (int64_t)g.n * g.k;
   const int64_t words = (int64_t)(g.k / 32) * g.n;   // one thread per (column, 32-k step)
   if (g.zmode == kZeroAwq) {
     hipLaunchKernelGGL((w4_dequant_pack_kernel<T, kZeroAwq>), dim3((words + 255) / 256), dim3(256), 0,
@@ -256,18 +296,23 @@ static int run_unfused(const GemmArgs& g) {
   }
   int rc = check_launch("w4_dequant_pack");
   if (rc) return rc;
-  const int m_tiles = (g.m + 15) / 16;
-  hipLaunchKernelGGL(pack_a_kernel<T>, dim3((g.k + kPackK - 1) / kPackK, m_tiles), dim3(256), 0, g.stream,
-                     packed_a, static_cast<const T*>(g.a), g.m, g.k, g.lda);
-  rc = check_launch("pack_a");
-  if (rc) return rc;
+  if (g.a_packed) {
+    packed_a = static_cast<const T*>(g.a);   // the producer already wrote the operand image
+  } else {
+    const int m_tiles = (g.m + 15) / 16;
+    hipLaunchKernelGGL(pack_a_kernel<T>, dim3((g.k + kPackK - 1) / kPackK, m_tiles), dim3(256), 0,
+                       g.stream, packed_b + (int64_t)g.n * g.k, static_cast<const T*>(g.a), g.m, g.k,
+                       g.lda);
+    rc = check_launch("pack_a");
+    if (rc) return rc;
+  }
   const int num_m_blocks = (g.m + kUfBM - 1) / kUfBM;
   // SILU: a tile = 128 gate + 128 up columns, i.e. one block per 128 output columns
   const int num_n_blocks = SILU ? (g.n / 2 + 127) / 128 : (g.n + kUfBN - 1) / kUfBN;
   const int num_tiles = num_m_blocks * num_n_blocks;
   const size_t smem = (size_t)kUfStages * 2048 * sizeof(uint4);  // 128 KiB
-  auto kern = gemm_packed_kernel<T, SILU>;
-  static bool attr_set = false;  // one flag per instantiation (T, SILU)
+  auto kern = gemm_packed_kernel<T, MODE>;
+  static bool attr_set = false;  // one flag per instantiation (T, MODE)
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -291,12 +336,18 @@ int w4a16_gemm_unfused_dispatch(const GemmArgs& g, int dtype) {
   if (g.m < 1024) return 1;   // too few 256-row tiles to fill 256 CUs below that
   if (g.fuse_silu) {
     if (g.n % 256 != 0) return 1;   // gate and up halves must each be whole 128-column blocks
-    if (dtype == MI355X_BF16) return run_unfused<bf16_t, true>(g);
-    if (dtype == MI355X_F16) return run_unfused<f16_t, true>(g);
+    if (g.out_packed) {
+      if (dtype == MI355X_BF16) return run_unfused<bf16_t, 2>(g);
+      if (dtype == MI355X_F16) return run_unfused<f16_t, 2>(g);
+      return 1;
+    }
+    if (dtype == MI355X_BF16) return run_unfused<bf16_t, 1>(g);
+    if (dtype == MI355X_F16) return run_unfused<f16_t, 1>(g);
     return 1;
   }
-  if (dtype == MI355X_BF16) return run_unfused<bf16_t, false>(g);
-  if (dtype == MI355X_F16) return run_unfused<f16_t, false>(g);
+  if (g.out_packed) return 1;
+  if (dtype == MI355X_BF16) return run_unfused<bf16_t, 0>(g);
+  if (dtype == MI355X_F16) return run_unfused<f16_t, 0>(g);
   return 1;
 }
 

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import dataclasses
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -97,6 +98,7 @@ class QLinear:
         self._ws = {}
 
     _shared_ws = {}   # device -> fp32 split-K scratch shared by every layer (stream-ordered use)
+    packed_silu = os.environ.get("MI355X_PACKED_SILU", "1") != "0"   # A/B switch for the bench
 
     def _workspace(self, m: int, device):
         """fp32 scratch for the split-K partial slabs of the decode GEMM: up to 8 slabs of
@@ -109,8 +111,10 @@ class QLinear:
             QLinear._shared_ws[device] = ws
         return ws
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    def __call__(self, x) -> torch.Tensor:
         m = x.shape[0]
+        if isinstance(x, ops.PackedOperand):     # prefill: activations already re-tiled by the producer
+            return ops.awq_gemm_packed_a(x, self.qweight, self.qzeros, self.scales)
         if self.quant == "awq":
             ws = self._workspace(m, x.device) if m <= 64 else torch.empty(0)
             return ops.awq_gemm(x, self.qweight, self.qzeros, self.scales, 8, ws,
@@ -136,6 +140,11 @@ class QLinear:
     def silu_mul(self, x: torch.Tensor):
         """silu_and_mul(self(x)) in one launch where the library supports it (AWQ, M >= 1024), else None."""
         if self.quant == "awq":
+            if x.shape[0] >= 1024 and self.packed_silu:
+                # the result goes straight into the operand image of the next (down_proj) GEMM
+                out = ops.awq_gemm_silu_mul_packed(x, self.qweight, self.qzeros, self.scales)
+                if out is not None:
+                    return out
             return ops.awq_gemm_silu_mul(x, self.qweight, self.qzeros, self.scales)
         return None
 
