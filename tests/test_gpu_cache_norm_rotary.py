@@ -347,7 +347,7 @@ def test_silu_and_mul(dtype, d_, tokens):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("sk", [0, 3])
-@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (8, 2, 64)])
+@pytest.mark.parametrize("H,KVH,D", [(32, 8, 128), (8, 2, 64), (6, 3, 128), (5, 1, 256)])   # last two: head groups straddle q|k|v
 def test_qkv_rope_cache_matches_the_three_ops(dtype, sk, H, KVH, D):
     """MI355X-side decode fusion: [slab sum +] rotary + reshape_and_cache in one launch must give
     exactly the bits of the reference-op sequence (oracle: R.rotary_embedding / R.reshape_and_cache)."""
@@ -382,6 +382,8 @@ def test_qkv_rope_cache_matches_the_three_ops(dtype, sk, H, KVH, D):
                          slots.to(d), H, KVH, D)
     assert_bit_exact(qkv_d[:, :H * D].contiguous(), ref_q.contiguous(), "q")
     assert_bit_exact(qkv_d[:, H * D:(H + KVH) * D].contiguous(), ref_k.contiguous(), "k")
+    if sk:
+        assert_bit_exact(qkv_d[:, (H + KVH) * D:].contiguous(), v.contiguous(), "v (from the slabs)")
     assert_bit_exact(kc_d, ref_kc, "key_cache")
     assert_bit_exact(vc_d, ref_vc, "value_cache")
 

@@ -5,10 +5,10 @@
 //   [T(sum of the GEMM's split-K slabs)]            (w4a16_sum_slabs_kernel, when sk > 0)
 //   rotary_embedding(positions, q, k)  NeoX          (csrc/pos_encoding_kernels.cu:10-34, :37-100)
 //   reshape_and_cache(k, v, key_cache, value_cache)  (csrc/cache_kernels.cu:203-255)
-// One workgroup per token: the qkv row (<= 16 KiB) is staged in LDS, rotated there, then q goes
-// back to the qkv buffer (the attention kernel reads it from there) and k / v are scattered
-// into the token's slot of the paged x-split cache.  Decode rows are launch-bound (64 tokens x
-// 12 KiB): the three launches cost ~15 us per layer, this one ~5.
+// One workgroup per (token, group of ~8 heads of the row's q | k | v head list): its columns are
+// staged in LDS, rotated there, then q goes back to the qkv buffer (the attention kernel reads it
+// from there) and k / v are scattered into the token's slot of the paged x-split cache.  Decode
+// rows are launch-bound (64 tokens x 12 KiB): the three launches cost ~15 us per layer.
 #include "common.cuh"
 
 namespace mi355x {
@@ -19,21 +19,26 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
     int64_t slab_stride, const int64_t* __restrict__ positions, const T* __restrict__ cos_sin_cache,
     T* __restrict__ key_cache, T* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping,
     int num_heads, int num_kv_heads, int head_size, int block_size, int64_t key_block_stride,
-    int64_t value_block_stride) {
+    int64_t value_block_stride, int heads_per_wg) {
   constexpr int V = 16 / sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // grid (token, head group): a workgroup owns heads [h0, h1) of the row's q | k | v head list, so
+  // a 64-token decode batch is 384 workgroups instead of 64
   T* row = reinterpret_cast<T*>(smem);
   const int64_t token = blockIdx.x;
-  const int q_size = num_heads * head_size;
-  const int kv_size = num_kv_heads * head_size;
-  const int width = q_size + 2 * kv_size;
-  T* grow = qkv + token * qkv_stride;
+  const int total_heads = num_heads + 2 * num_kv_heads;
+  const int h0 = blockIdx.y * heads_per_wg;
+  const int h1 = min(h0 + heads_per_wg, total_heads);
+  const int c0 = h0 * head_size;                 // first column of this workgroup
+  const int cols = (h1 - h0) * head_size;
+  const int width = total_heads * head_size;
+  T* grow = qkv + token * qkv_stride + c0;
 
-  // 1. the row, as T
-  for (int i = threadIdx.x * V; i < width; i += blockDim.x * V) {
+  // 1. the columns, as T
+  for (int i = threadIdx.x * V; i < cols; i += blockDim.x * V) {
     if (sk > 0) {
       float acc[V];
-      const float* sp = slabs + token * width + i;
+      const float* sp = slabs + token * width + c0 + i;
 #pragma unroll
       for (int j = 0; j < V; ++j) acc[j] = sp[j];
       for (int s = 1; s < sk; ++s) {
@@ -53,44 +58,52 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
   // 2. NeoX rotary on the q and k heads (rot_dim == head_size), in LDS
   const int embed = head_size / 2;
   const int cph = embed / V;
-  const int64_t pos = positions[token];
-  const T* cos_ptr = cos_sin_cache + pos * head_size;
-  const T* sin_ptr = cos_ptr + embed;
-  for (int i = threadIdx.x; i < (num_heads + num_kv_heads) * cph; i += blockDim.x) {
-    const int h = i / cph;
-    const int c = i - h * cph;
-    T* base = row + h * head_size;        // q heads, then the k heads follow contiguously
-    Vec16<T> x = load16(base + c * V);
-    Vec16<T> y = load16(base + embed + c * V);
-    const Vec16<T> cs = load16(cos_ptr + c * V);
-    const Vec16<T> sn = load16(sin_ptr + c * V);
+  const int rot_heads = min(h1, num_heads + num_kv_heads) - h0;     // <= 0: v heads only
+  if (rot_heads > 0) {
+    const int64_t pos = positions[token];
+    const T* cos_ptr = cos_sin_cache + pos * head_size;
+    const T* sin_ptr = cos_ptr + embed;
+    for (int i = threadIdx.x; i < rot_heads * cph; i += blockDim.x) {
+      const int h = i / cph;
+      const int c = i - h * cph;
+      T* base = row + h * head_size;
+      Vec16<T> x = load16(base + c * V);
+      Vec16<T> y = load16(base + embed + c * V);
+      const Vec16<T> cs = load16(cos_ptr + c * V);
+      const Vec16<T> sn = load16(sin_ptr + c * V);
 #pragma unroll
-    for (int j = 0; j < V; ++j) rot_pair<T>(x.e[j], y.e[j], cs.e[j], sn.e[j]);
-    store16(base + c * V, x);
-    store16(base + embed + c * V, y);
+      for (int j = 0; j < V; ++j) rot_pair<T>(x.e[j], y.e[j], cs.e[j], sn.e[j]);
+      store16(base + c * V, x);
+      store16(base + embed + c * V, y);
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
-  // 3. q (and, when the row came from slabs, k and v too) back to the qkv buffer; k / v into the cache
-  const int back = sk > 0 ? width : q_size + kv_size;   // v is unchanged when it was read from qkv
-  for (int i = threadIdx.x * V; i < back; i += blockDim.x * V) store16(grow + i, load16(row + i));
+  // 3. q and k (and, when the row came from slabs, v too) back to the qkv buffer; k / v into the cache
+  const int back = (sk > 0 ? h1 : min(h1, num_heads + num_kv_heads)) - h0;   // v unchanged when read from qkv
+  for (int i = threadIdx.x * V; i < back * head_size; i += blockDim.x * V) {
+    store16(grow + i, load16(row + i));
+  }
   const int64_t slot = slot_mapping[token];
   if (slot < 0) return;
   const int64_t blk = slot / block_size;
   const int t = (int)(slot - blk * block_size);
   const int cpk = head_size / V;          // 16-byte chunks per head
-  const T* krow = row + q_size;
-  const T* vrow = krow + kv_size;
-  for (int i = threadIdx.x; i < num_kv_heads * cpk; i += blockDim.x) {
-    const int h = i / cpk;
-    const int c = i - h * cpk;
+  const int k_lo = max(h0, num_heads), k_hi = min(h1, num_heads + num_kv_heads);
+  for (int i = threadIdx.x; i < (k_hi - k_lo) * cpk; i += blockDim.x) {
+    const int hh = i / cpk;
+    const int c = i - hh * cpk;
+    const int h = k_lo + hh - num_heads;                               // kv head
     T* dst = key_cache + blk * key_block_stride + ((int64_t)(h * cpk + c) * block_size + t) * V;
-    store16(dst, load16(krow + h * head_size + c * V));
+    store16(dst, load16(row + (k_lo + hh - h0) * head_size + c * V));
   }
-  for (int i = threadIdx.x; i < kv_size; i += blockDim.x) {
-    const int h = i / head_size;
-    const int d = i - h * head_size;
-    value_cache[blk * value_block_stride + ((int64_t)(h * head_size + d)) * block_size + t] = vrow[i];
+  const int v_lo = max(h0, num_heads + num_kv_heads);
+  for (int i = threadIdx.x; i < (h1 - v_lo) * head_size; i += blockDim.x) {
+    const int hh = i / head_size;
+    const int d = i - hh * head_size;
+    const int h = v_lo + hh - num_heads - num_kv_heads;                // kv head
+    value_cache[blk * value_block_stride + ((int64_t)(h * head_size + d)) * block_size + t] =
+        row[(v_lo + hh - h0) * head_size + d];
   }
 }
 
@@ -114,20 +127,27 @@ extern "C" int mi355x_qkv_rope_cache(void* qkv, int64_t qkv_stride, const float*
   MI355X_REQUIRE(dtype == MI355X_BF16 || dtype == MI355X_F16, MI355X_EUNSUPPORTED,
                  "qkv_rope_cache: 2-byte dtypes only");
   const int width = (num_heads + 2 * num_kv_heads) * head_size;
-  MI355X_REQUIRE(x == 8 && head_size % 16 == 0 && qkv_stride % 8 == 0 && width * 2 <= 64 * 1024,
+  MI355X_REQUIRE(x == 8 && head_size % 16 == 0 && qkv_stride % 8 == 0 && head_size <= 8192,
                  MI355X_EUNSUPPORTED,
-                 "qkv_rope_cache: needs x == 8, head_size %% 16 == 0, qkv_stride %% 8 == 0, row <= 64 KiB");
+                 "qkv_rope_cache: needs x == 8, head_size %% 16 == 0 (<= 8192), qkv_stride %% 8 == 0");
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   MI355X_REQUIRE(al(qkv) && al(cos_sin_cache) && al(key_cache) && (sk == 0 || (slabs && al(slabs))),
                  MI355X_EINVAL, "qkv_rope_cache: pointers must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
   return MI355X_DISPATCH_HALF(dtype, [&] {
-    hipLaunchKernelGGL(qkv_rope_cache_kernel<scalar_t>, dim3(num_tokens), dim3(256),
-                       (size_t)width * sizeof(scalar_t), s, static_cast<scalar_t*>(qkv), qkv_stride,
+    // ~1024 columns per workgroup (8 heads of 128), 16 B per thread
+    const int total_heads = num_heads + 2 * num_kv_heads;
+    int hp = 1024 / head_size;
+    hp = hp < 1 ? 1 : (hp > total_heads ? total_heads : hp);
+    const int chunks = hp * head_size / 8;
+    const int threads = chunks >= 256 ? 256 : (chunks + 63) / 64 * 64;
+    hipLaunchKernelGGL(qkv_rope_cache_kernel<scalar_t>, dim3(num_tokens, (total_heads + hp - 1) / hp),
+                       dim3(threads), (size_t)hp * head_size * sizeof(scalar_t), s,
+                       static_cast<scalar_t*>(qkv), qkv_stride,
                        sk > 0 ? slabs : nullptr, sk, (int64_t)num_tokens * width, positions,
                        static_cast<const scalar_t*>(cos_sin_cache), static_cast<scalar_t*>(key_cache),
                        static_cast<scalar_t*>(value_cache), slot_mapping, num_heads, num_kv_heads,
-                       head_size, block_size, key_block_stride, value_block_stride);
+                       head_size, block_size, key_block_stride, value_block_stride, hp);
     return check_launch("qkv_rope_cache");
   });
 }
