@@ -201,6 +201,46 @@ __device__ __forceinline__ uint16_t f32x2_to_fp8x2_sat(float a, float b) {
   return static_cast<uint16_t>(packed & 0xffff);
 }
 
+// ---- split-K slab sum ------------------------------------------------------------
+// acc[j] = slab[0][j] + slab[1][j] + ... + slab[sk-1][j] in THAT order (the consumers of the
+// decode GEMM's fp32 partials must all round the same sum), V consecutive floats per lane.  The
+// loads of up to 8 slabs are issued before the first add: a loop of load -> add would pay one
+// memory round trip per slab, which is most of the time of the launch-bound decode consumers.
+template <int V>
+__device__ __forceinline__ void sum_slabs(const float* __restrict__ sp, int sk, int64_t stride,
+                                          float (&acc)[V]) {
+  constexpr int kMax = 8;
+  float v[kMax][V];
+#pragma unroll
+  for (int s = 0; s < kMax; ++s) {
+    if (s < sk) {
+      if constexpr (V % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+          *reinterpret_cast<float4*>(&v[s][j]) =
+              *reinterpret_cast<const float4*>(sp + (int64_t)s * stride + j);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < V; ++j) v[s][j] = sp[(int64_t)s * stride + j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = v[0][j];
+#pragma unroll
+  for (int s = 1; s < kMax; ++s) {
+    if (s < sk) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += v[s][j];
+    }
+  }
+  for (int s = kMax; s < sk; ++s) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] += sp[(int64_t)s * stride + j];
+  }
+}
+
 // ---- dtype dispatch ------------------------------------------------------------
 #define MI355X_DISPATCH_FLOAT(dtype, ...)                                \
   [&]() -> int {                                                         \

@@ -38,13 +38,7 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
   for (int i = threadIdx.x * V; i < cols; i += blockDim.x * V) {
     if (sk > 0) {
       float acc[V];
-      const float* sp = slabs + token * width + c0 + i;
-#pragma unroll
-      for (int j = 0; j < V; ++j) acc[j] = sp[j];
-      for (int s = 1; s < sk; ++s) {
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] += sp[(int64_t)s * slab_stride + j];
-      }
+      sum_slabs<V>(slabs + token * width + c0 + i, sk, slab_stride, acc);
       Vec16<T> v;
 #pragma unroll
       for (int j = 0; j < V; ++j) v.e[j] = from_f32<T>(acc[j]);

@@ -48,13 +48,7 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
       if (slabs != nullptr) {
         // same arithmetic as w4a16_sum_slabs_kernel: fp32 sum in slab order, one rounding to T
         float acc[V];
-        const float* sp = slabs + row * hidden_size + idx;
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] = sp[j];
-        for (int s2 = 1; s2 < sk; ++s2) {
-#pragma unroll
-          for (int j = 0; j < V; ++j) acc[j] += sp[(int64_t)s2 * slab_stride + j];
-        }
+        sum_slabs<V>(slabs + row * hidden_size + idx, sk, slab_stride, acc);
 #pragma unroll
         for (int j = 0; j < V; ++j) iv[j] = from_f32<T>(acc[j]);
         if (res_row) {

@@ -155,16 +155,9 @@ __global__ void w4a16_sum_slabs_kernel(T* __restrict__ out, const float* __restr
                                        int64_t n4, int sk) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
-  const float4* p = reinterpret_cast<const float4*>(slabs) + i;
-  float4 v = p[0];
-  for (int s = 1; s < sk; ++s) {
-    const float4 u = p[(int64_t)s * n4];
-    v.x += u.x;
-    v.y += u.y;
-    v.z += u.z;
-    v.w += u.w;
-  }
-  T o[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
+  float v[4];
+  sum_slabs<4>(slabs + i * 4, sk, n4 * 4, v);
+  T o[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
   reinterpret_cast<uint2*>(out)[i] = *reinterpret_cast<const uint2*>(o);
 }
 
