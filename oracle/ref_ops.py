@@ -117,7 +117,9 @@ def paged_attention_v1(query, key_cache, value_cache, num_kv_heads, scale, block
         if L == 0:
             continue
         for h in range(H):
-            k, v = _gather_kv(key_cache, value_cache, block_tables[s], L, h // G)
+            if h % G == 0:      # the G query heads of a kv head share one gathered (fp32) K / V
+                k, v = _gather_kv(key_cache, value_cache, block_tables[s], L, h // G)
+                k, v = k.float(), v.float()
             bias = None
             if alibi_slopes is not None and float(alibi_slopes[h]) != 0.0:
                 pos = torch.arange(L, dtype=torch.float32)
@@ -146,7 +148,9 @@ def paged_attention_v2(query, key_cache, value_cache, num_kv_heads, scale, block
         for h in range(H):
             if L == 0:
                 continue
-            k, v = _gather_kv(key_cache, value_cache, block_tables[s], L, h // G)
+            if h % G == 0:
+                k, v = _gather_kv(key_cache, value_cache, block_tables[s], L, h // G)
+                k, v = k.float(), v.float()
             for p in range(np_):
                 lo, hi = p * PARTITION_SIZE, min((p + 1) * PARTITION_SIZE, L)
                 bias = None
