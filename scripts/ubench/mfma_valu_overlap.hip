@@ -8,6 +8,22 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// the VALU instruction under test: -DVALU_OP=0 v_pk_fma_f32 (default), 1 v_fma_f32, 2 v_and_b32,
+// 3 v_cvt_f32_ubyte0, 4 v_cvt_pk_bf16_f32
+#ifndef VALU_OP
+#define VALU_OP 0
+#endif
+#if VALU_OP == 0
+#define VALU(r) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(m), "v"(c))
+#elif VALU_OP == 1
+#define VALU(r) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[r][0]) : "v"(m[0]), "v"(c[0]))
+#elif VALU_OP == 2
+#define VALU(r) asm volatile("v_and_b32 %0, %0, %1" : "+v"(v[r][0]) : "v"(m[0]))
+#elif VALU_OP == 3
+#define VALU(r) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(v[r][0]))
+#else
+#define VALU(r) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[r][0]) : "v"(m[0]))
+#endif
 
 // MODE 0: MFMA only; 1: VALU only; 2: both, interleaved 1 MFMA : 4 VALU in every wave;
 // 3: waves 0-3 MFMA only (2x the rounds' MFMAs), waves 4-7 VALU only (2x the VALU): same total work
@@ -33,7 +49,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = (4 * i + j) & 7;
-          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(m), "v"(c));
+          VALU(r);
         }
       }
     } else {
@@ -44,7 +60,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
       if (do_valu) {
 #pragma unroll
         for (int i = 0; i < 64; ++i)
-          asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v[i & 7]) : "v"(m), "v"(c));
+          VALU(i & 7);
       }
     }
   }
@@ -74,7 +90,7 @@ int main() {
   // cycles per round per SIMD at 2.4 GHz (2 waves per SIMD)
   auto cyc = [&](float ms) { return ms * 1e-3 * 2.4e9 / iters; };
   printf("MFMA only              : %7.2f ms  %6.0f cycles per round and SIMD (2 x 16 MFMAs)\n", t0, cyc(t0));
-  printf("VALU only              : %7.2f ms  %6.0f cycles (2 x 64 v_pk_fma_f32)\n", t1, cyc(t1));
+  printf("VALU only              : %7.2f ms  %6.0f cycles (2 x 64 VALU ops, -DVALU_OP)\n", t1, cyc(t1));
   printf("both, interleaved      : %7.2f ms  %6.0f cycles\n", t2, cyc(t2));
   printf("both, split by wave    : %7.2f ms  %6.0f cycles\n", t3, cyc(t3));
   printf("both, MFMAs then VALU  : %7.2f ms  %6.0f cycles\n", t4, cyc(t4));

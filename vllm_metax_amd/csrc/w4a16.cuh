@@ -62,17 +62,24 @@ template <typename T>
 __device__ __forceinline__ uint4 dequant_word(uint32_t w, float s, float zs) {
   const uint32_t t0 = w & 0x0F0F0F0Fu;         // bytes: k0, k4, k1, k5
   const uint32_t t1 = (w >> 4) & 0x0F0F0F0Fu;  // bytes: k2, k6, k3, k7
-  // element pairs go through v_pk_fma_f32 (two IEEE fmas per instruction, s / zs broadcast)
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  const f32x2_t s2 = {s, s}, z2 = {zs, zs};
   f32x2_t k01 = {cvt_ubyte0(t0), cvt_ubyte2(t0)};
   f32x2_t k23 = {cvt_ubyte0(t1), cvt_ubyte2(t1)};
   f32x2_t k45 = {cvt_ubyte1(t0), cvt_ubyte3(t0)};
   f32x2_t k67 = {cvt_ubyte1(t1), cvt_ubyte3(t1)};
-  k01 = __builtin_elementwise_fma(k01, s2, z2);
-  k23 = __builtin_elementwise_fma(k23, s2, z2);
-  k45 = __builtin_elementwise_fma(k45, s2, z2);
-  k67 = __builtin_elementwise_fma(k67, s2, z2);
+  // eight v_fma_f32, not four v_pk_fma_f32: next to MFMAs the packed form is the slower one
+  // (scripts/ubench/mfma_valu_overlap.hip: 128 v_pk_fma_f32 + 32 MFMAs per SIMD take 1412 cycles,
+  // more than the 549 + 609 they take apart; 128 v_fma_f32 + 32 MFMAs 819) — gate_up at M = 64
+  // 36.5 -> 34.5 us.  Inline asm: the vectoriser would fuse the pairs back into v_pk_fma_f32.
+  auto f = [&](float q) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(q), "v"(s), "v"(zs));
+    return r;
+  };
+  k01 = f32x2_t{f(k01.x), f(k01.y)};
+  k23 = f32x2_t{f(k23.x), f(k23.y)};
+  k45 = f32x2_t{f(k45.x), f(k45.y)};
+  k67 = f32x2_t{f(k67.x), f(k67.y)};
   uint4 r;
   r.x = Mfma<T>::pack(k01.x, k01.y);
   r.y = Mfma<T>::pack(k23.x, k23.y);
