@@ -42,6 +42,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+MFMA_8BIT_PEAK_TFLOPS = 5000.0  # dense fp8 / int8 MFMA peak (the --quant fp8 / int8 GEMMs)
 WEIGHT_FORMAT = {"awq": "w4a16 g128", "gptq": "w4a16 g128", "fp8": "w8a8 fp8", "int8": "w8a8 int8",
                  "none": "bf16"}
 
@@ -369,9 +370,11 @@ def main():
         avg_ms = d["ms"] / d["launches"]
         if d["flops"] > 0 and name.endswith("large_m") or name == "paged_prefill_attention":
             ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+            peak = MFMA_8BIT_PEAK_TFLOPS if name.startswith(("fp8_gemm", "int8_gemm")) \
+                else MFMA_BF16_PEAK_TFLOPS
             return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2),
-                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
                     "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
                     "total_ms": round(d["ms"], 2)}
         ach = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
