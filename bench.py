@@ -226,6 +226,13 @@ def cpu_baseline(args, cfg):
     from oracle import ref_ops as R
     import numpy as np
     torch.manual_seed(0)
+    # a 1-GPU box grants ~16 of the host's hardware threads: a team as wide as the machine only
+    # fights over them (measured: 0.7-1.1 tokens/s with 128 threads, 1.6 with 8)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    C.set_num_threads(min(16, avail))
     B, ctx = args.batch, args.input_len + args.output_len // 2
     h, d, H, KVH, ffn, g = cfg.hidden, cfg.head_dim, cfg.heads, cfg.kv_heads, cfg.ffn, cfg.group_size
     bf = torch.bfloat16
@@ -263,8 +270,15 @@ def cpu_baseline(args, cfg):
         return C.w4a16_gemm(act, *[W["down"][i] for i in (0, 2, 1)], 0, g)
 
     layer()  # warm (page in, thread pool)
-    t0 = time.perf_counter(); layer(); t_layer = time.perf_counter() - t0
-    t0 = time.perf_counter(); C.gemm_bf16(x, lm); t_head = time.perf_counter() - t0
+    reps = 8
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        layer()
+    t_layer = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        C.gemm_bf16(x, lm)
+    t_head = (time.perf_counter() - t0) / reps
     # job estimate: every token position (prefill + decode) pays the per-token layer cost of
     # the M=64 sample; prefill attention is NOT counted (under-estimates CPU time).
     positions = args.batch * (args.input_len + args.output_len - 1)
@@ -276,7 +290,8 @@ def cpu_baseline(args, cfg):
         "cores": C.num_threads(),
         "kind": "port",
         "sample": (f"oracle/cpu_port.c: 1 of {cfg.layers} decoder layers at batch {B}, ctx {ctx} "
-                   f"({t_layer:.2f} s) + lm_head ({t_head:.2f} s); job time extrapolated as "
+                   f"({t_layer:.2f} s, mean of {reps}) + lm_head ({t_head:.2f} s, mean of {reps}); "
+                   f"job time extrapolated as "
                    f"layers x per-64-token layer cost x {steps_equiv:.0f} token groups + {args.output_len} "
                    f"lm_head calls, prefill attention not counted"),
     }

@@ -36,6 +36,15 @@ static inline bf16 f2bf(float f) {
   return (bf16)(c.u >> 16);
 }
 
+/* cap the OpenMP team (a GPU box shows every hardware thread of the host but grants a share) */
+void cpu_port_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int cpu_port_num_threads(void) {
   int n = 1;
 #ifdef _OPENMP

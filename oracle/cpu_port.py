@@ -39,6 +39,10 @@ def num_threads() -> int:
     return lib().cpu_port_num_threads()
 
 
+def set_num_threads(n: int) -> None:
+    lib().cpu_port_set_num_threads(int(n))
+
+
 def rms_norm(x, w, eps):
     out = torch.empty_like(x)
     lib().cpu_rms_norm_bf16(_p(out), _p(x), _p(w), ctypes.c_float(eps), x.shape[0], x.shape[1])
