@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 1
+#define MI355X_ABI_VERSION 2
 
 typedef enum {
   MI355X_F16 = 0,  /* IEEE half  (torch.float16)  */
@@ -40,6 +40,16 @@ enum {
   MI355X_EUNSUPPORTED = -2,/* shape / dtype / feature outside the supported set        */
   MI355X_ELAUNCH = -3      /* hipLaunch / hipMemcpyAsync reported an error             */
 };
+
+/* kv_cache_dtype of the cache / attention entry points (the schema's `str kv_cache_dtype`):
+ * "auto" = the cache holds scalar_t; "fp8" / "fp8_e4m3" = OCP e4m3fn bytes, x = 16
+ * (cache byte = sat_e4m3(float(x) / *k_scale), value = float(byte) * *k_scale; likewise V).
+ * The reference's dispatch accepts only "auto" (csrc/quantization/fp8/metax/quant_utils.cuh:29-42);
+ * the fp8 cache is SURVEY §8f-3, hook points csrc/cache_kernels.cu:245-253,258-269. */
+typedef enum {
+  MI355X_KV_AUTO = 0,
+  MI355X_KV_FP8_E4M3 = 1
+} mi355x_kv_cache_dtype;
 
 typedef void* mi355x_stream; /* hipStream_t */
 
@@ -63,7 +73,8 @@ int mi355x_reshape_and_cache(const void* key, const void* value, void* key_cache
                              void* value_cache, const int64_t* slot_mapping,
                              int num_tokens, int64_t key_stride, int64_t value_stride,
                              int num_heads, int head_size, int block_size, int x,
-                             int dtype, mi355x_stream stream);
+                             int dtype, int kv_cache_dtype, const float* k_scale,
+                             const float* v_scale, mi355x_stream stream);
 
 /* reshape_and_cache_flash: same into NHD [num_blocks, block_size, heads, head_size]
  * (or HND through the strides). num_tokens = slot_mapping.size(0).
@@ -74,7 +85,14 @@ int mi355x_reshape_and_cache_flash(const void* key, const void* value, void* key
                                    int64_t page_stride, int64_t head_stride,
                                    int64_t key_stride, int64_t value_stride,
                                    int num_heads, int head_size, int block_size,
-                                   int dtype, mi355x_stream stream);
+                                   int dtype, int kv_cache_dtype, const float* k_scale,
+                                   const float* v_scale, mi355x_stream stream);
+
+/* convert_fp8: elementwise over a flat cache of `numel` elements.  to_fp8 != 0: src scalar_t ->
+ * dst e4m3 byte = sat(float(x) / scale); else src byte -> dst scalar_t = T(float(byte) * scale).
+ * ref: csrc/cache_kernels.cu:544-612 ("only for testing" there), schema torch_bindings.cpp:424. */
+int mi355x_convert_fp8(void* dst, const void* src, int64_t numel, float scale, int to_fp8,
+                       int dtype, mi355x_stream stream);
 
 /* copy_blocks: for every layer l and pair p copy block src->dst inside
  * key_caches[l] and value_caches[l]. `key_cache_ptrs`/`value_cache_ptrs` are HOST
@@ -98,8 +116,8 @@ int mi355x_swap_blocks(const void* src, void* dst, const int64_t* block_mapping,
  * Single-query (decode) attention over the x-split paged KV cache.
  *   out/query [num_seqs, num_heads, head_size] (query row stride = q_stride)
  *   block_tables int32 [num_seqs, max_num_blocks_per_seq]; seq_lens int32 [num_seqs]
- *   alibi_slopes float [num_heads] or NULL. kv cache dtype is always "auto"
- *   (== query dtype), as in the reference (quant_utils.cuh:29-42).
+ *   alibi_slopes float [num_heads] or NULL. kv_cache_dtype: mi355x_kv_cache_dtype; k_scale /
+ *   v_scale: device pointers to one float each (read only for the fp8 cache; block sizes 16, 32).
  * One workgroup serves ALL query heads of one KV head (GQA reuse), unlike the
  * reference's one block per query head.
  * ref: csrc/attention/paged_attention_v1.cu:43-125,160-182;
@@ -111,7 +129,16 @@ int mi355x_paged_attention_v1(void* out, const void* query, const void* key_cach
                               const int* seq_lens, int max_num_blocks_per_seq,
                               int max_seq_len, const float* alibi_slopes,
                               int64_t q_stride, int64_t kv_block_stride,
-                              int64_t kv_head_stride, int dtype, mi355x_stream stream);
+                              int64_t kv_head_stride, int dtype, int kv_cache_dtype,
+                              const float* k_scale, const float* v_scale, mi355x_stream stream);
+
+/* Largest max_seq_len mi355x_paged_attention_v1 accepts for this head geometry: v1 keeps the
+ * logits of a whole sequence for all (<= 4) query heads of a KV head in one workgroup's LDS
+ * (160 KiB); beyond it the caller must use _v2.  The reference sizes its LDS the same way
+ * (csrc/attention/paged_attention_v1.cu:77-87) and leaves the v1 / v2 choice to its caller.
+ * Pure host function (no launch).  Returns the limit (a multiple of 64) or a negative code. */
+int mi355x_paged_attention_v1_max_seq_len(int num_seqs, int num_heads, int num_kv_heads,
+                                          int head_size, int block_size, int dtype);
 
 /* Split-KV variant: partitions of MI355X_PA_PARTITION_SIZE tokens, then an
  * LSE-rescaled reduce.  exp_sums/max_logits float [num_seqs, num_heads, P],
@@ -127,7 +154,8 @@ int mi355x_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
                               const int* seq_lens, int max_num_blocks_per_seq,
                               int max_seq_len, const float* alibi_slopes,
                               int64_t q_stride, int64_t kv_block_stride,
-                              int64_t kv_head_stride, int dtype, mi355x_stream stream);
+                              int64_t kv_head_stride, int dtype, int kv_cache_dtype,
+                              const float* k_scale, const float* v_scale, mi355x_stream stream);
 
 /* Paged prefill / chunked prefill (varlen, causal bottom-right aligned, GQA) over
  * the SAME x-split paged cache (the new tokens were already written by
@@ -144,7 +172,8 @@ int mi355x_paged_prefill_attention(void* out, const void* query, const void* key
                                    int max_query_len, int max_num_blocks_per_seq,
                                    int64_t q_stride, int64_t out_stride,
                                    int64_t kv_block_stride, int64_t kv_head_stride,
-                                   int dtype, mi355x_stream stream);
+                                   int dtype, int kv_cache_dtype, const float* k_scale,
+                                   const float* v_scale, mi355x_stream stream);
 
 /* ------------------------------------------------------------- layernorm --
  * ref: csrc/layernorm_kernels.cu:141-162 (rms_norm), :174-217 (fused_add). */

@@ -77,6 +77,36 @@ def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping) -> None:
         dst[d].copy_(src[s])
 
 
+# ====================================================================== fp8 (e4m3fn) KV cache
+# SURVEY §8f-3.  The reference carries the hook (cache_kernels.cu:245-253 scaled_convert in the
+# cache write, :258-269 CopyWithScaleOp, :544-612 convert_fp8, attention_kernels.cuh:266-277 /
+# :398-407 on the read side) but its dispatch rejects everything except "auto"
+# (quantization/fp8/metax/quant_utils.cuh:29-42), so the arithmetic restated here is upstream
+# vLLM's: byte = sat_e4m3(float(x) / scale) (RNE), value = T(float(byte) * scale).
+# Layout: x = 16 / sizeof(cache_t) = 16: key_cache [nb, H, D/16, bs, 16] bytes, value_cache
+# [nb, H, D, bs] bytes.  parity unpinned by a reference run (rejected there); the read side is
+# pinned through the reference's own test procedure (dequantise, then its torch attention
+# reference: tests/kernels/attention/test_attention.py:303-328, fixture ref_paged_attention_fp8kv).
+def fp8_quant(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """scalar_t -> e4m3 bytes (uint8 tensor)."""
+    return _to_fp8_sat(x.float() / np.float32(scale)).view(torch.uint8)
+
+
+def fp8_dequant(b: torch.Tensor, scale: float, dtype) -> torch.Tensor:
+    """e4m3 bytes -> T(float(byte) * scale)."""
+    return (b.view(FP8).float() * np.float32(scale)).to(dtype)
+
+
+def reshape_and_cache_fp8(key, value, key_cache, value_cache, slot_mapping, k_scale, v_scale) -> None:
+    """reshape_and_cache with kv_cache_dtype "fp8": caches are uint8, x = 16."""
+    reshape_and_cache(fp8_quant(key, k_scale), fp8_quant(value, v_scale), key_cache, value_cache, slot_mapping)
+
+
+def reshape_and_cache_flash_fp8(key, value, key_cache, value_cache, slot_mapping, k_scale, v_scale) -> None:
+    reshape_and_cache_flash(fp8_quant(key, k_scale), fp8_quant(value, v_scale), key_cache, value_cache,
+                            slot_mapping)
+
+
 # =========================================================================== attention
 def _gather_kv(key_cache, value_cache, block_table, seq_len, kv_head):
     """K [L, D], V [L, D] of one sequence / kv head from the x-split paged layout."""

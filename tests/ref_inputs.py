@@ -61,6 +61,27 @@ def decode_inputs(m):
     return q.to(dt), kc.to(dt), vc.to(dt), bt, sl, slopes
 
 
+def decode_inputs_fp8(m):
+    """fp8 (e4m3fn) KV cache in the x = 16 layout: (q, key_cache u8 [nb,kvh,d/16,bs,16],
+    value_cache u8 [nb,kvh,d,bs], block_tables, seq_lens, slopes).  Bytes = e4m3 of U(-1, 1)."""
+    dt = DT[m["dtype"]]
+    H, KVH, d, bs, nb, seed = m["H"], m["KVH"], m["d"], m["bs"], m["nb"], m["seed"]
+    S = len(m["seq_lens"])
+    q = D.normalish((S, H, d), seed + 2, 1.0).to(dt)
+    kc = D.uniform((nb, KVH, d // 16, bs, 16), seed, -1.0, 1.0).to(FP8).view(torch.uint8)
+    vc = D.uniform((nb, KVH, d, bs), seed + 1, -1.0, 1.0).to(FP8).view(torch.uint8)
+    mb = (max(m["seq_lens"]) + bs - 1) // bs
+    bt = D.randint((S, mb), seed + 3, 0, nb).to(torch.int32)
+    sl = torch.tensor(m["seq_lens"], dtype=torch.int32)
+    slopes = D.normalish((H,), seed + 4, 1.0) if m["alibi"] else None
+    return q, kc, vc, bt, sl, slopes
+
+
+def fp8_cache_to(cache_u8, scale, dtype):
+    """e4m3 bytes -> dtype values float(byte) * scale (exact for scale 1: e4m3 is a subset)."""
+    return (cache_u8.view(FP8).float() * scale).to(dtype)
+
+
 # ------------------------------------------------------------------ prefill attention
 def prefill_inputs(m):
     """(q [T,H,d], key_cache NHD [nb,bs,kvh,d], value_cache NHD, block_tables) — all bf16."""

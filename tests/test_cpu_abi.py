@@ -43,17 +43,24 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     # and the ctypes prototype table covers exactly the header
     assert sorted(built.PROTOTYPES) == header_symbols()
-    assert lib.mi355x_abi_version() == 1
+    assert lib.mi355x_abi_version() == 2
 
 
 def test_argument_errors_surface_without_a_gpu(built):
     """Validation happens on the host before any launch, so these are safe on CPU."""
     lib = built.load()
     rc = lib.mi355x_paged_attention_v1(None, None, None, None, 4, 32, 8, 72, 16, 1.0, None, None,
-                                       4, 64, None, 0, 0, 0, built.BF16, None)
+                                       4, 64, None, 0, 0, 0, built.BF16, built.KV_AUTO, None, None, None)
     assert rc == -2 and "Unsupported head size" in built.last_error()
+    rc = lib.mi355x_paged_attention_v1(None, None, None, None, 4, 32, 8, 128, 16, 1.0, None, None,
+                                       4, 64, None, 0, 0, 0, built.BF16, 7, None, None, None)
+    assert rc == -1 or "kv cache" in built.last_error()
     rc = lib.mi355x_awq_gemm(None, None, None, None, None, None, 0, None, 0, 4, 100, 512, 128, 512, built.BF16, None)
-    assert rc == -2 and "multiple of 64" in built.last_error()
+    assert rc == -2 and "multiple of 8" in built.last_error()
+    # v1 keeps the logits of a whole sequence in LDS: the limit the backend's v1 / v2 choice uses
+    assert lib.mi355x_paged_attention_v1_max_seq_len(64, 32, 8, 128, 16, built.BF16) == 6720
+    assert lib.mi355x_paged_attention_v1_max_seq_len(64, 32, 8, 128, 16, built.F32) == 4928
+    assert lib.mi355x_paged_attention_v1_max_seq_len(64, 32, 32, 128, 16, built.BF16) == 27200
     rc = lib.mi355x_gptq_gemm(None, None, None, None, None, None, None, None, 0, None, 0, 4, 128, 512, 3, 128,
                               built.BF16, None)
     assert rc == -2 and "4-bit" in built.last_error()
@@ -69,6 +76,8 @@ def test_ops_raise_on_cpu_tensors(built):
         ops.rms_norm(torch.empty_like(x), x, torch.ones(64, dtype=torch.bfloat16), 1e-5)
     with pytest.raises(RuntimeError):
         ops.reshape_and_cache(x, x, x, x, torch.zeros(2, dtype=torch.int64), "fp8")
+    with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
+        ops.reshape_and_cache(x, x, x, x, torch.zeros(2, dtype=torch.int64), "fp8_e5m2")
 
 
 def test_torch_bindings_register_reference_op_names(built):
@@ -81,7 +90,7 @@ def test_torch_bindings_register_reference_op_names(built):
                  "dynamic_scaled_fp8_quant", "dynamic_per_token_scaled_fp8_quant", "silu_and_mul",
                  "silu_and_mul_quant", "weak_ref_tensor"]:
         assert hasattr(torch.ops._C, name), name
-    for name in ["reshape_and_cache", "reshape_and_cache_flash", "copy_blocks", "swap_blocks"]:
+    for name in ["reshape_and_cache", "reshape_and_cache_flash", "copy_blocks", "swap_blocks", "convert_fp8"]:
         assert hasattr(torch.ops._C_cache_ops, name), name
     assert hasattr(torch.ops._C_cuda_utils, "get_device_attribute")
     # schema strings are the reference's (torch_bindings.cpp:45-55, 233-236)

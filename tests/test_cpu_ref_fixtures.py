@@ -183,3 +183,19 @@ def test_dynamic_quant_reference_bit_exact():
             # below -127, which it cannot
             assert_bit_exact(q, RI.arr(z, i, "q"), f"quant[{i}] q")
         assert np.array_equal(s.reshape(-1).numpy(), ref_s.reshape(-1).numpy()), f"quant[{i}] scales"
+
+
+# ------------------------------------------------------------------------------ f3 (fp8 KV cache)
+def test_paged_attention_fp8kv_reference():
+    """fp8 KV cache, the reference's test procedure (test_attention.py:303-328): the cache is
+    dequantised (scale 1.0, exact) and its torch attention reference evaluated; the oracle's fp8 read
+    path (fp8_dequant + paged_attention_v1/v2) must agree with that."""
+    z, meta = RI.load("ref_paged_attention_fp8kv")
+    for i, m in enumerate(meta):
+        q, kc8, vc8, bt, sl, slopes = RI.decode_inputs_fp8(m)
+        RI.check_crc(m, q=q, kc=kc8, vc=vc8)
+        kc, vc = R.fp8_dequant(kc8, 1.0, q.dtype), R.fp8_dequant(vc8, 1.0, q.dtype)
+        ref32 = RI.arr(z, i, "out_f32")
+        close_to_f32(R.paged_attention_v1(q, kc, vc, m["KVH"], m["scale"], bt, sl, slopes), ref32, f"fp8kv[{i}] v1")
+        close_to_f32(R.paged_attention_v2(q, kc, vc, m["KVH"], m["scale"], bt, sl, int(sl.max()), slopes)[0],
+                     ref32, f"fp8kv[{i}] v2")

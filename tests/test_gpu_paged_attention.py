@@ -240,3 +240,48 @@ def test_decode_attention_bench_shape_properties():
                      1e-3, "v2 sub-batch", abs_floor=_tol(o2.cpu()))
     perm = torch.randperm(S, device=d)
     assert torch.equal(v1(q[perm].contiguous(), bt[perm].contiguous(), sl[perm].contiguous()), o1[perm])
+
+
+@pytest.mark.parametrize("dtype,max_len,expect_v1", [
+    (torch.bfloat16, 6720, True), (torch.bfloat16, 7000, False), (torch.bfloat16, 8192, False),
+    (torch.float32, 4928, True), (torch.float32, 5100, False)])
+def test_decode_attention_v1_v2_boundary(dtype, max_len, expect_v1):
+    """Round-1 defect (VERDICT / ADVICE): the backend chose v1 for every max_seq_len <= 8192, but v1 keeps
+    4 heads' logits in one workgroup's LDS and its launcher refuses contexts past 6720 (bf16) / 4928
+    (fp32) at 32/8 heads, so decode_attention raised.  The choice now comes from the launcher's budget
+    (mi355x_paged_attention_v1_max_seq_len) and falls to v2; both sides of the boundary match the oracle."""
+    from vllm_metax_amd.attention import backend as B
+    S, H, KVH, D, BS = 17, 32, 8, 128, 16                       # 17 x 32 > 512 (seq, head) pairs
+    assert B.use_paged_attention_v1(S, H, max_len, KVH, D, BS, dtype) is expect_v1
+    seq_lens = [1 + (i * 13) % 60 for i in range(S)]
+    seq_lens[3] = max_len
+    args = _setup(S, H, KVH, D, BS, dtype, seq_lens, seed=9, num_blocks=max_len // BS + 64)
+    q, kc, vc, bt, sl, slopes, scale, _ = args
+    d = dev()
+    P = (max_len + 511) // 512
+    out = torch.full_like(q, float("nan"), device=d)
+    es = torch.empty(S, H, P, dtype=torch.float32, device=d)
+    B.decode_attention(out, es, torch.empty_like(es), torch.empty(S, H, P, D, dtype=dtype, device=d), q.to(d),
+                       kc.to(d), vc.to(d), KVH, scale, bt.to(d), sl.to(d), BS, max_len)
+    torch.cuda.synchronize()
+    rows = [0, 3, 16]                                            # oracle on the long row and two short ones
+    ref = R.paged_attention_v1(q[rows], kc, vc, KVH, scale, bt[rows], sl[rows])
+    assert_close_rel(out[rows], ref, 1e-3, f"decode_attention max_len {max_len}", abs_floor=_tol(ref))
+    # and the launcher itself still refuses what does not fit (the message names the limit query)
+    if not expect_v1:
+        with pytest.raises(RuntimeError, match="paged_attention_v2"):
+            ops().paged_attention_v1(out, q.to(d), kc.to(d), vc.to(d), KVH, scale, bt.to(d), sl.to(d), BS, max_len,
+                                     None, "auto")
+
+
+def test_paged_attention_tp8_per_rank_heads():
+    """Per-rank head shape of Llama-3-70B / Qwen2-72B at TP=8: 8 query heads, ONE kv head
+    (two head tiles of 4 per workgroup column), contexts across partition boundaries."""
+    seq_lens = [1, 16, 511, 513, 1151, 2049]
+    for dtype in (torch.bfloat16, torch.float16):
+        args = _setup(len(seq_lens), 8, 1, 128, 16, dtype, seq_lens, seed=21)
+        q, kc, vc, bt, sl, slopes, scale, max_len = args
+        ref1 = R.paged_attention_v1(q, kc, vc, 1, scale, bt, sl, slopes)
+        assert_close_rel(_run_v1(*args, 1, 16), ref1, 1e-3, "v1 8q/1kv", abs_floor=_tol(ref1))
+        ref2 = R.paged_attention_v2(q, kc, vc, 1, scale, bt, sl, max_len, slopes)[0]
+        assert_close_rel(_run_v2(*args, 1, 16)[0], ref2, 1e-3, "v2 8q/1kv", abs_floor=_tol(ref2))

@@ -15,6 +15,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libmi355x_hotpath.so"
 
 F16, BF16, F32 = 0, 1, 2
+KV_AUTO, KV_FP8_E4M3 = 0, 1          # mi355x_kv_cache_dtype
 
 _P = c_void_p
 _I = c_int
@@ -27,18 +28,23 @@ PROTOTYPES = {
     "mi355x_last_error": (c_char_p, []),
     "mi355x_get_device_attribute": (_L, [_L, _L]),
     "mi355x_get_max_shared_memory_per_block_device_attribute": (_L, [_L]),
-    "mi355x_reshape_and_cache": (_I, [_P, _P, _P, _P, _P, _I, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "mi355x_reshape_and_cache": (
+        _I, [_P, _P, _P, _P, _P, _I, _L, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "mi355x_reshape_and_cache_flash": (
-        _I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _I, _P]),
+        _I, [_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "mi355x_convert_fp8": (_I, [_P, _P, _L, _F, _I, _I, _P]),
     "mi355x_copy_blocks": (_I, [_P, _P, _I, _P, _I, _L, _P]),
     "mi355x_swap_blocks": (_I, [_P, _P, _P, _I, _L, _I, _P]),
     "mi355x_paged_attention_v1": (
-        _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _L, _L, _L, _I, _P]),
+        _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _L, _L, _L, _I, _I, _P, _P,
+             _P]),
+    "mi355x_paged_attention_v1_max_seq_len": (_I, [_I, _I, _I, _I, _I, _I]),
     "mi355x_paged_attention_v2": (
         _I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _L, _L, _L,
-             _I, _P]),
+             _I, _I, _P, _P, _P]),
     "mi355x_paged_prefill_attention": (
-        _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _I, _L, _L, _L, _L, _I, _P]),
+        _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _I, _L, _L, _L, _L, _I, _I, _P,
+             _P, _P]),
     "mi355x_rms_norm": (_I, [_P, _P, _P, _F, _I, _I, _L, _I, _P]),
     "mi355x_fused_add_rms_norm": (_I, [_P, _P, _P, _F, _I, _I, _L, _I, _P]),
     "mi355x_fused_add_rms_norm_slabs": (_I, [_P, _P, _P, _P, _I, _F, _I, _I, _L, _I, _P]),

@@ -48,10 +48,22 @@ def _dev(*ts: Optional[torch.Tensor]) -> None:
             raise RuntimeError("expected a tensor on the GPU (hip) device, got " + str(t.device))
 
 
-def _check_kv_dtype(kv_cache_dtype: str) -> None:
-    # ref: csrc/quantization/fp8/metax/quant_utils.cuh:29-42 — only "auto" is accepted
-    if kv_cache_dtype != "auto":
-        raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+def _kv_dtype(kv_cache_dtype: str, cache: torch.Tensor, k_scale, v_scale):
+    """`str kv_cache_dtype` of the schema -> (mi355x_kv_cache_dtype, k_scale ptr, v_scale ptr).
+    "auto": the cache holds scalar_t (all the reference accepts: csrc/quantization/fp8/metax/
+    quant_utils.cuh:29-42).  "fp8" / "fp8_e4m3": OCP e4m3fn bytes (upstream vLLM's
+    names), cache tensors of dtype uint8 / float8_e4m3fn, k_scale / v_scale one float32 each on the
+    device.  Anything else raises like the reference's TORCH_CHECK."""
+    if kv_cache_dtype == "auto":
+        return _abi.KV_AUTO, None, None
+    if kv_cache_dtype in ("fp8", "fp8_e4m3"):
+        if cache.element_size() != 1:
+            raise RuntimeError(f"kv_cache_dtype {kv_cache_dtype!r} needs a 1-byte cache, got {cache.dtype}")
+        for name, t in (("k_scale", k_scale), ("v_scale", v_scale)):
+            if t is None or not t.is_cuda or t.dtype != torch.float32 or t.numel() != 1:
+                raise RuntimeError(f"{name} must be one float32 element on the GPU for an fp8 KV cache")
+        return _abi.KV_FP8_E4M3, _ptr(k_scale), _ptr(v_scale)
+    raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
 
 
 # ----------------------------------------------------------------------------- utils
@@ -74,7 +86,7 @@ def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.T
                       value_cache: torch.Tensor, slot_mapping: torch.Tensor,
                       kv_cache_dtype: str = "auto", k_scale: Optional[torch.Tensor] = None,
                       v_scale: Optional[torch.Tensor] = None) -> None:
-    _check_kv_dtype(kv_cache_dtype)
+    kvd, ks, vs = _kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale)
     _dev(key, value, key_cache, value_cache, slot_mapping)
     if slot_mapping.dtype != torch.int64:
         raise RuntimeError("slot_mapping must be int64")
@@ -84,7 +96,7 @@ def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.T
     rc = _abi.load().mi355x_reshape_and_cache(
         _ptr(key), _ptr(value), _ptr(key_cache), _ptr(value_cache), _ptr(slot_mapping),
         num_tokens, key.stride(0), value.stride(0), num_heads, head_size, block_size, x,
-        _dt(key), _stream())
+        _dt(key), kvd, ks, vs, _stream())
     _abi.check(rc, "reshape_and_cache")
 
 
@@ -93,7 +105,7 @@ def reshape_and_cache_flash(key: torch.Tensor, value: torch.Tensor, key_cache: t
                             kv_cache_dtype: str = "auto",
                             k_scale: Optional[torch.Tensor] = None,
                             v_scale: Optional[torch.Tensor] = None) -> None:
-    _check_kv_dtype(kv_cache_dtype)
+    kvd, ks, vs = _kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale)
     _dev(key, value, key_cache, value_cache, slot_mapping)
     if slot_mapping.dtype != torch.int64:
         raise RuntimeError("slot_mapping must be int64")
@@ -104,8 +116,26 @@ def reshape_and_cache_flash(key: torch.Tensor, value: torch.Tensor, key_cache: t
         _ptr(key), _ptr(value), _ptr(key_cache), _ptr(value_cache), _ptr(slot_mapping),
         num_tokens, key_cache.stride(0), key_cache.stride(1), key_cache.stride(2),
         key.stride(0), value.stride(0), key.size(1), key.size(2), key_cache.size(1),
-        _dt(key), _stream())
+        _dt(key), kvd, ks, vs, _stream())
     _abi.check(rc, "reshape_and_cache_flash")
+
+
+def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0,
+                kv_dtype: str = "fp8") -> None:
+    """torch.ops._C_cache_ops.convert_fp8 (csrc/torch_bindings.cpp:424-426, cache_kernels.cu:564-612):
+    elementwise over the flat cache; direction from the dtypes (1-byte side = e4m3 bytes)."""
+    _dev(output, input)
+    if kv_dtype not in ("fp8", "fp8_e4m3"):
+        raise RuntimeError(f"Unsupported data type: {kv_dtype}")
+    if output.numel() != input.numel() or not (output.is_contiguous() and input.is_contiguous()):
+        raise RuntimeError("convert_fp8: tensors must be contiguous and of the same size")
+    to_fp8 = output.element_size() == 1
+    wide = input if to_fp8 else output
+    if (input if to_fp8 else output).element_size() == 1 or (output if to_fp8 else input).element_size() != 1:
+        raise RuntimeError("convert_fp8: exactly one of the tensors must be a 1-byte (fp8) tensor")
+    rc = _abi.load().mi355x_convert_fp8(_ptr(output), _ptr(input), input.numel(), float(scale),
+                                        1 if to_fp8 else 0, _dt(wide), _stream())
+    _abi.check(rc, "convert_fp8")
 
 
 def copy_blocks(key_caches: Sequence[torch.Tensor], value_caches: Sequence[torch.Tensor],
@@ -162,7 +192,7 @@ def paged_attention_v1(out: torch.Tensor, query: torch.Tensor, key_cache: torch.
                        blocksparse_local_blocks: int = 0, blocksparse_vert_stride: int = 0,
                        blocksparse_block_size: int = 64,
                        blocksparse_head_sliding_step: int = 0) -> None:
-    _check_kv_dtype(kv_cache_dtype)
+    kvd, ks, vs = _kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale)
     _check_blocksparse(blocksparse_vert_stride)
     _dev(out, query, key_cache, value_cache, block_tables, seq_lens, alibi_slopes)
     if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
@@ -172,7 +202,7 @@ def paged_attention_v1(out: torch.Tensor, query: torch.Tensor, key_cache: torch.
         query.size(1), num_kv_heads, query.size(2), block_size, float(scale),
         _ptr(block_tables), _ptr(seq_lens), block_tables.size(1), max_seq_len,
         _ptr(alibi_slopes), query.stride(0), key_cache.stride(0), key_cache.stride(1),
-        _dt(query), _stream())
+        _dt(query), kvd, ks, vs, _stream())
     _abi.check(rc, "paged_attention_v1")
 
 
@@ -186,7 +216,7 @@ def paged_attention_v2(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: to
                        blocksparse_local_blocks: int = 0, blocksparse_vert_stride: int = 0,
                        blocksparse_block_size: int = 64,
                        blocksparse_head_sliding_step: int = 0) -> None:
-    _check_kv_dtype(kv_cache_dtype)
+    kvd, ks, vs = _kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale)
     _check_blocksparse(blocksparse_vert_stride)
     _dev(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, block_tables,
          seq_lens, alibi_slopes)
@@ -197,25 +227,39 @@ def paged_attention_v2(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: to
         _ptr(key_cache), _ptr(value_cache), query.size(0), query.size(1), num_kv_heads,
         query.size(2), block_size, float(scale), _ptr(block_tables), _ptr(seq_lens),
         block_tables.size(1), max_seq_len, _ptr(alibi_slopes), query.stride(0),
-        key_cache.stride(0), key_cache.stride(1), _dt(query), _stream())
+        key_cache.stride(0), key_cache.stride(1), _dt(query), kvd, ks, vs, _stream())
     _abi.check(rc, "paged_attention_v2")
+
+
+def paged_attention_v1_max_seq_len(num_seqs: int, num_heads: int, num_kv_heads: int, head_size: int,
+                                   block_size: int, dtype: torch.dtype) -> int:
+    """Largest max_seq_len paged_attention_v1 takes for this geometry (its logits live in one
+    workgroup's 160 KiB of LDS); longer contexts must go to paged_attention_v2."""
+    v = _abi.load().mi355x_paged_attention_v1_max_seq_len(num_seqs, num_heads, num_kv_heads, head_size,
+                                                         block_size, _DT[dtype])
+    if v < 0:
+        raise RuntimeError(_abi.last_error())
+    return v
 
 
 def paged_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
                             value_cache: torch.Tensor, num_kv_heads: int, scale: float,
                             block_tables: torch.Tensor, seq_lens: torch.Tensor,
                             cu_seqlens_q: torch.Tensor, max_query_len: int,
-                            block_size: int) -> None:
+                            block_size: int, kv_cache_dtype: str = "auto",
+                            k_scale: Optional[torch.Tensor] = None,
+                            v_scale: Optional[torch.Tensor] = None) -> None:
     """Varlen causal attention of the new tokens against the paged cache (the role of
     flash_attn_varlen_func(block_table=...) at the reference call site
     vllm_metax/v1/attention/backends/flash_attn.py:725-747)."""
     _dev(out, query, key_cache, value_cache, block_tables, seq_lens, cu_seqlens_q)
+    kvd, ks, vs = _kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale)
     rc = _abi.load().mi355x_paged_prefill_attention(
         _ptr(out), _ptr(query), _ptr(key_cache), _ptr(value_cache), seq_lens.size(0),
         query.size(1), num_kv_heads, query.size(2), block_size, float(scale),
         _ptr(block_tables), _ptr(seq_lens), _ptr(cu_seqlens_q), max_query_len,
         block_tables.size(1), query.stride(0), out.stride(0), key_cache.stride(0),
-        key_cache.stride(1), _dt(query), _stream())
+        key_cache.stride(1), _dt(query), kvd, ks, vs, _stream())
     _abi.check(rc, "paged_prefill_attention")
 
 

@@ -18,6 +18,7 @@ classes at the bottom are thin and only defined when vLLM imports.
 from __future__ import annotations
 
 import dataclasses
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -46,10 +47,44 @@ class Mi355xPagedMetadata:
     max_decode_seq_len: int = 0
     max_prefill_query_len: int = 0
     prefill_query_start_loc: Optional[torch.Tensor] = None  # int32 [Rp+1], rebased to 0
-    # split-KV workspaces for the decode kernel (allocated once per step, shared by all layers)
+    # split-KV workspaces for the decode kernel (shared by all layers; views of the builder's
+    # persistent buffers when a DecodeWorkspace is given, so that a captured graph never writes to
+    # freed memory)
     exp_sums: Optional[torch.Tensor] = None
     max_logits: Optional[torch.Tensor] = None
     tmp_out: Optional[torch.Tensor] = None
+    # v1 / v2 decided once per step from the launcher's own LDS budget (None: decide per call)
+    use_v1: Optional[bool] = None
+
+
+class DecodeWorkspace:
+    """Split-KV buffers of paged_attention_v2, allocated ONCE for (max_num_seqs, ceil(max_model_len /
+    512)) and handed out as views.  build() used to torch.empty() them per step: under a full HIP-graph
+    capture the graph keeps the capture-time addresses, which the allocator may have reused by replay
+    time.  Invariant: every pointer a captured decode launch sees belongs to a buffer that
+    outlives the graph."""
+
+    def __init__(self, max_num_seqs: int, num_heads: int, head_size: int, max_model_len: int,
+                 dtype: torch.dtype, device):
+        self.max_num_seqs = max_num_seqs
+        self.max_parts = max((max_model_len + PARTITION_SIZE - 1) // PARTITION_SIZE, 1)
+        self.max_model_len = max_model_len
+        self.exp_sums = torch.empty(max_num_seqs, num_heads, self.max_parts, dtype=torch.float32, device=device)
+        self.max_logits = torch.empty_like(self.exp_sums)
+        self.tmp_out = torch.empty(max_num_seqs, num_heads, self.max_parts, head_size, dtype=dtype, device=device)
+
+    def views(self, num_seqs: int, parts: int):
+        if num_seqs > self.max_num_seqs or parts > self.max_parts:
+            raise RuntimeError(f"decode workspace too small: {num_seqs} seqs x {parts} partitions "
+                               f"(sized for {self.max_num_seqs} x {self.max_parts})")
+        n = num_seqs
+        h, d = self.exp_sums.shape[1], self.tmp_out.shape[-1]
+        # contiguous [n, h, parts(, d)] views of the flat storage: the kernels index with `parts` as the
+        # partition stride, so the views must be dense in the shape they are launched with
+        es = self.exp_sums.view(-1)[:n * h * parts].view(n, h, parts)
+        ml = self.max_logits.view(-1)[:n * h * parts].view(n, h, parts)
+        to = self.tmp_out.view(-1)[:n * h * parts * d].view(n, h, parts, d)
+        return es, ml, to
 
 
 def split_decodes_and_prefills(query_lens_cpu, decode_threshold: int = 1) -> Tuple[int, int, int, int]:
@@ -71,7 +106,9 @@ def split_decodes_and_prefills(query_lens_cpu, decode_threshold: int = 1) -> Tup
 def build_metadata(query_start_loc: torch.Tensor, query_start_loc_cpu, seq_lens: torch.Tensor,
                    seq_lens_cpu, block_table: torch.Tensor, slot_mapping: torch.Tensor,
                    num_actual_tokens: int, max_query_len: int, max_seq_len: int, num_heads: int,
-                   head_size: int, dtype: torch.dtype) -> Mi355xPagedMetadata:
+                   head_size: int, dtype: torch.dtype, workspace: Optional[DecodeWorkspace] = None,
+                   num_kv_heads: Optional[int] = None, block_size: int = 16,
+                   fixed_decode_len: Optional[int] = None) -> Mi355xPagedMetadata:
     """Everything forward() needs, computed once per step (cf. flash_attn.py:286-526).
     `*_cpu` are host copies (lists / CPU tensors) that vLLM's CommonAttentionMetadata already
     carries, so no device->host sync happens here either."""
@@ -86,11 +123,21 @@ def build_metadata(query_start_loc: torch.Tensor, query_start_loc_cpu, seq_lens:
         num_prefill_tokens=npt)
     dev = seq_lens.device
     if nd > 0:
-        md.max_decode_seq_len = max(sl_cpu[:nd]) if sl_cpu else 0
+        # `fixed_decode_len` (HIP-graph capture / replay): every host-side decision of the decode
+        # launch — v1 vs v2, the partition count = grid.z, the LDS size — is taken from this fixed
+        # value instead of the batch's current maximum, so a replay with longer sequences stays inside
+        # what was captured (the kernels read the true lengths from seq_lens on the device)
+        md.max_decode_seq_len = fixed_decode_len if fixed_decode_len else (max(sl_cpu[:nd]) if sl_cpu else 0)
         parts = max((md.max_decode_seq_len + PARTITION_SIZE - 1) // PARTITION_SIZE, 1)
-        md.exp_sums = torch.empty(nd, num_heads, parts, dtype=torch.float32, device=dev)
-        md.max_logits = torch.empty_like(md.exp_sums)
-        md.tmp_out = torch.empty(nd, num_heads, parts, head_size, dtype=dtype, device=dev)
+        if workspace is not None:
+            md.exp_sums, md.max_logits, md.tmp_out = workspace.views(nd, parts)
+        else:
+            md.exp_sums = torch.empty(nd, num_heads, parts, dtype=torch.float32, device=dev)
+            md.max_logits = torch.empty_like(md.exp_sums)
+            md.tmp_out = torch.empty(nd, num_heads, parts, head_size, dtype=dtype, device=dev)
+        if num_kv_heads is not None:
+            md.use_v1 = use_paged_attention_v1(nd, num_heads, md.max_decode_seq_len, num_kv_heads, head_size,
+                                               block_size, dtype)
     if npf > 0:
         md.max_prefill_query_len = max(q_lens[nd:])
         md.prefill_query_start_loc = (query_start_loc[nd:] - query_start_loc[nd:nd + 1]).to(torch.int32)
@@ -110,37 +157,61 @@ def split_kv_cache(kv_cache: torch.Tensor, num_kv_heads: int, head_size: int):
     return key_cache, value_cache
 
 
-def use_paged_attention_v1(num_seqs: int, num_heads: int, max_seq_len: int) -> bool:
+@functools.lru_cache(maxsize=None)
+def v1_max_seq_len(num_heads: int, num_kv_heads: int, head_size: int, block_size: int,
+                   dtype: torch.dtype) -> int:
+    """Largest context paged_attention_v1 takes for this head geometry: the launcher's own LDS budget
+    (mi355x_paged_attention_v1_max_seq_len; the reference sizes its LDS the same way,
+    csrc/attention/paged_attention_v1.cu:77-87) — 6720 tokens for 32/8 heads in bf16, 4928 in fp32."""
+    return ops.paged_attention_v1_max_seq_len(1, num_heads, num_kv_heads, head_size, block_size, dtype)
+
+
+def v1_v2_rule(num_seqs: int, num_heads: int, max_seq_len: int, v1_limit: int) -> bool:
     """The v1 / v2 choice of the upstream caller (vllm/attention/ops/paged_attn.py,
-    PagedAttention.forward_decode): v1 when the context fits one workgroup's LDS and either a single
-    512-token partition covers it or there are already > 512 (sequence, head) pairs to spread."""
+    PagedAttention.forward_decode: v1 when max_seq_len <= 8192 and either a single 512-token partition
+    covers it or there are already > 512 (sequence, head) pairs to spread) with its fixed 8192 replaced
+    by what one workgroup's LDS really holds for this geometry (`v1_limit`): beyond it only v2 runs."""
     max_parts = (max_seq_len + 511) // 512
-    return max_seq_len <= 8192 and (max_parts == 1 or num_seqs * num_heads > 512)
+    return max_seq_len <= min(8192, v1_limit) and (max_parts == 1 or num_seqs * num_heads > 512)
+
+
+def use_paged_attention_v1(num_seqs: int, num_heads: int, max_seq_len: int, num_kv_heads: int,
+                           head_size: int, block_size: int, dtype: torch.dtype) -> bool:
+    return v1_v2_rule(num_seqs, num_heads, max_seq_len,
+                      v1_max_seq_len(num_heads, num_kv_heads, head_size, block_size, dtype))
 
 
 def decode_attention(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torch.Tensor,
                      tmp_out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
                      value_cache: torch.Tensor, num_kv_heads: int, scale: float,
                      block_table: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
-                     max_seq_len: int, alibi_slopes: Optional[torch.Tensor] = None) -> None:
+                     max_seq_len: int, alibi_slopes: Optional[torch.Tensor] = None,
+                     kv_cache_dtype: str = "auto", k_scale: Optional[torch.Tensor] = None,
+                     v_scale: Optional[torch.Tensor] = None, use_v1: Optional[bool] = None) -> None:
     """paged_attention_v1 or _v2, chosen like the upstream caller the reference plugs into
     (vllm/attention/ops/paged_attn.py, PagedAttention.forward_decode): v1 when the context is
     short enough for one workgroup's LDS and there is already enough parallelism without
     partitioning (num_seqs * num_heads > 512), else the 512-token-partition kernel + reduce.
     Measured at 64 seqs x 32 heads, ctx 1088: v1 63.9 us, v2 67.1 us (scripts/bench_attn.py)."""
-    if use_paged_attention_v1(query.shape[0], query.shape[1], max_seq_len):
+    if use_v1 is None:
+        use_v1 = use_paged_attention_v1(query.shape[0], query.shape[1], max_seq_len, num_kv_heads,
+                                        query.shape[2], block_size, query.dtype)
+    if use_v1:
         ops.paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale, block_table,
-                               seq_lens, block_size, max_seq_len, alibi_slopes, "auto")
+                               seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, k_scale,
+                               v_scale)
     else:
         ops.paged_attention_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache,
                                num_kv_heads, scale, block_table, seq_lens, block_size, max_seq_len,
-                               alibi_slopes, "auto")
+                               alibi_slopes, kv_cache_dtype, k_scale, v_scale)
 
 
 def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
                             value: Optional[torch.Tensor], kv_cache: torch.Tensor,
                             md: Mi355xPagedMetadata, output: torch.Tensor, num_kv_heads: int,
-                            scale: float, alibi_slopes: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            scale: float, alibi_slopes: Optional[torch.Tensor] = None,
+                            kv_cache_dtype: str = "auto", k_scale: Optional[torch.Tensor] = None,
+                            v_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """query [T, H, d], key/value [T, KVH, d] (may be padded past num_actual_tokens),
     output [T, H, d] caller-provided (accept_output_buffer, flash_attn.py:56)."""
     head_size = query.shape[-1]
@@ -149,18 +220,21 @@ def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
     n = md.num_actual_tokens
     if key is not None and value is not None:
         # slot_mapping.size(0) is the number of real tokens (cache_kernels.cu:459-469)
-        ops.reshape_and_cache(key, value, key_cache, value_cache, md.slot_mapping[:n], "auto")
+        ops.reshape_and_cache(key, value, key_cache, value_cache, md.slot_mapping[:n], kv_cache_dtype,
+                              k_scale, v_scale)
     nd, ndt = md.num_decodes, md.num_decode_tokens
     if nd > 0:
         decode_attention(output[:ndt], md.exp_sums, md.max_logits, md.tmp_out, query[:ndt],
                          key_cache, value_cache, num_kv_heads, scale, md.block_table[:nd],
-                         md.seq_lens[:nd], block_size, md.max_decode_seq_len, alibi_slopes)
+                         md.seq_lens[:nd], block_size, md.max_decode_seq_len, alibi_slopes,
+                         kv_cache_dtype, k_scale, v_scale, md.use_v1)
     if md.num_prefills > 0:
         if alibi_slopes is not None:
             raise RuntimeError("ALiBi is only supported on the decode path of this backend")
         ops.paged_prefill_attention(output[ndt:n], query[ndt:n], key_cache, value_cache,
                                     num_kv_heads, scale, md.block_table[nd:], md.seq_lens[nd:],
-                                    md.prefill_query_start_loc, md.max_prefill_query_len, block_size)
+                                    md.prefill_query_start_loc, md.max_prefill_query_len, block_size,
+                                    kv_cache_dtype, k_scale, v_scale)
     return output
 
 
@@ -178,28 +252,52 @@ try:  # pragma: no cover - needs upstream vLLM
             super().__init__(kv_cache_spec, layer_names, vllm_config, device)
             mc = vllm_config.model_config
             self.num_heads = mc.get_num_attention_heads(vllm_config.parallel_config)
+            self.num_kv_heads = mc.get_num_kv_heads(vllm_config.parallel_config)
             self.head_size = mc.get_head_size()
             self.dtype = mc.dtype
+            self.block_size = kv_cache_spec.block_size
+            self.max_model_len = mc.max_model_len
+            # persistent split-KV workspaces (never re-allocated: captured graphs hold their addresses)
+            self.workspace = DecodeWorkspace(vllm_config.scheduler_config.max_num_seqs, self.num_heads,
+                                             self.head_size, self.max_model_len, self.dtype, device)
+            self._capturing = False
 
         def build_for_cudagraph_capture(self, common_attn_metadata):
-            md = self.build(0, common_attn_metadata)
+            # Full-graph decode: every host-side launch decision is frozen at max_model_len (see
+            # build_metadata: fixed_decode_len), so a replay with longer sequences than the capture
+            # batch runs the same grid / LDS size / kernel; seq_lens = 1 keeps the capture run cheap.
+            self._capturing = True
+            try:
+                md = self.build(0, common_attn_metadata)
+            finally:
+                self._capturing = False
             md.seq_lens.fill_(1)                            # cf. triton_attn.py:93-99
             return md
 
         def build(self, common_prefix_len, common_attn_metadata: "CommonAttentionMetadata",
                   fast_build: bool = False):
             c = common_attn_metadata
+            # decode-only batches may be replayed from a full graph: keep them on the frozen geometry
+            decode_only = c.max_query_len == 1
+            fixed = self.max_model_len if (self._capturing or (decode_only and self._full_graphs())) else None
             return build_metadata(c.query_start_loc, c.query_start_loc_cpu, c.seq_lens,
                                   c.seq_lens_cpu, c.block_table_tensor, c.slot_mapping,
                                   c.num_actual_tokens, c.max_query_len, c.max_seq_len,
-                                  self.num_heads, self.head_size, self.dtype)
+                                  self.num_heads, self.head_size, self.dtype, self.workspace,
+                                  self.num_kv_heads, self.block_size, fixed)
+
+        def _full_graphs(self) -> bool:
+            cc = getattr(self.vllm_config, "compilation_config", None)
+            mode = getattr(cc, "cudagraph_mode", None)
+            return bool(mode is not None and getattr(mode, "has_full_cudagraphs", lambda: False)())
 
     class Mi355xPagedAttentionImpl(AttentionImpl):
         def __init__(self, num_heads, head_size, scale, num_kv_heads, alibi_slopes, sliding_window,
                      kv_cache_dtype, logits_soft_cap=None, attn_type=AttentionType.DECODER,
                      kv_sharing_target_layer_name=None, **kwargs):
-            if kv_cache_dtype != "auto":
+            if kv_cache_dtype not in ("auto", "fp8", "fp8_e4m3"):
                 raise ValueError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+            self.kv_cache_dtype = kv_cache_dtype
             if sliding_window is not None or logits_soft_cap:
                 raise NotImplementedError("sliding window / soft-cap are out of scope")
             if attn_type != AttentionType.DECODER:
@@ -220,9 +318,13 @@ try:  # pragma: no cover - needs upstream vLLM
             q3 = query.view(-1, self.num_heads, self.head_size)
             k3 = key.view(-1, self.num_kv_heads, self.head_size) if key is not None else None
             v3 = value.view(-1, self.num_kv_heads, self.head_size) if value is not None else None
+            fp8 = self.kv_cache_dtype != "auto"
+            if fp8 and kv_cache.dtype != torch.uint8:
+                kv_cache = kv_cache.view(torch.uint8)
             paged_attention_forward(q3, k3, v3, kv_cache, attn_metadata,
                                     output.view(-1, self.num_heads, self.head_size),
-                                    self.num_kv_heads, self.scale, slopes)
+                                    self.num_kv_heads, self.scale, slopes, self.kv_cache_dtype,
+                                    layer._k_scale if fp8 else None, layer._v_scale if fp8 else None)
             return output
 
     class Mi355xPagedAttentionBackend(AttentionBackend):

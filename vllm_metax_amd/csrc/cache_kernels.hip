@@ -5,6 +5,10 @@
 //   reshape_and_cache_flash  csrc/cache_kernels.cu:271-344, 450-488
 //   copy_blocks              csrc/cache_kernels.cu:65-91, 116-163
 //   swap_blocks              csrc/cache_kernels.cu:18-60
+//   fp8 (e4m3fn) KV cache     csrc/cache_kernels.cu:245-253, 258-269 (the scaled_convert hook of the
+//                             cache write), :544-612 (convert_fp8); the reference's own dispatch
+//                             rejects it (quant_utils.cuh:29-42), semantics are upstream vLLM's:
+//                             cache byte = sat_e4m3(float(x) / scale), value = T(float(byte) * scale)
 //
 // MI355X design: all HBM traffic is 16-byte per lane.  The reference's V scatter
 // (2-byte stores strided by block_size) is replaced by a 16-token tile that is
@@ -144,6 +148,142 @@ __global__ void reshape_and_cache_flash_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// fp8 (e4m3fn) cache.  key_cache [nb, heads, d/16, bs, 16] bytes (x = 16 / sizeof(cache_t) = 16),
+// value_cache [nb, heads, d, bs] bytes.  byte = sat_e4m3(float(x) / *scale), RNE.
+template <typename T>
+__device__ __forceinline__ uint4 quant16(const T* __restrict__ src, float scale) {
+  // 16 consecutive elements -> 16 fp8 bytes
+  constexpr int X = 16 / sizeof(T);
+  uint32_t w[4];
+  float f[16];
+#pragma unroll
+  for (int i = 0; i < 16 / X; ++i) {
+    const Vec16<T> v = load16<T>(src + i * X);
+#pragma unroll
+    for (int j = 0; j < X; ++j) f[i * X + j] = to_f32(v.e[j]) / scale;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w[i] = (uint32_t)f32x2_to_fp8x2_sat(f[4 * i], f[4 * i + 1]) |
+           ((uint32_t)f32x2_to_fp8x2_sat(f[4 * i + 2], f[4 * i + 3]) << 16);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Tiled path: grid (ceil(T/16), num_heads), 256 threads; head_size % 16 == 0, 16-B aligned rows.
+template <typename T>
+__global__ __launch_bounds__(256) void reshape_and_cache_fp8_tiled_kernel(
+    const T* __restrict__ key, const T* __restrict__ value, uint8_t* __restrict__ key_cache,
+    uint8_t* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, int num_tokens,
+    int64_t key_stride, int64_t value_stride, int num_heads, int head_size, int block_size,
+    const float* __restrict__ k_scale, const float* __restrict__ v_scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint8_t* vt = reinterpret_cast<uint8_t*>(smem_raw);            // [kTokTile][head_size + 16]
+  const int row = head_size + 16;
+  int64_t* s_blk = reinterpret_cast<int64_t*>(smem_raw + (size_t)kTokTile * row);
+  int* s_off = reinterpret_cast<int*>(s_blk + kTokTile);
+  const int t0 = blockIdx.x * kTokTile;
+  const int head = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int chunks = head_size / 16;
+  const float ks = *k_scale, vs = *v_scale;
+  if (tid < kTokTile) {
+    const int t = t0 + tid;
+    int64_t slot = (t < num_tokens) ? slot_mapping[t] : -1;
+    s_blk[tid] = slot < 0 ? -1 : slot / block_size;
+    s_off[tid] = slot < 0 ? 0 : static_cast<int>(slot % block_size);
+  }
+  __syncthreads();
+  for (int i = tid; i < kTokTile * chunks; i += blockDim.x) {
+    const int j = i / chunks;
+    const int c = i - j * chunks;
+    const int64_t blk = s_blk[j];
+    if (blk < 0) continue;
+    const int t = t0 + j;
+    const uint4 kq = quant16<T>(key + t * key_stride + (int64_t)head * head_size + c * 16, ks);
+    uint8_t* kdst = key_cache + (((blk * num_heads + head) * chunks + c) * block_size + s_off[j]) * 16;
+    *reinterpret_cast<uint4*>(kdst) = kq;
+    const uint4 vq = quant16<T>(value + t * value_stride + (int64_t)head * head_size + c * 16, vs);
+    *reinterpret_cast<uint4*>(vt + j * row + c * 16) = vq;
+  }
+  __syncthreads();
+  for (int i = tid; i < kTokTile * head_size; i += blockDim.x) {
+    const int j = i % kTokTile;
+    const int d = i / kTokTile;
+    const int64_t blk = s_blk[j];
+    if (blk < 0) continue;
+    value_cache[((blk * num_heads + head) * head_size + d) * block_size + s_off[j]] = vt[j * row + d];
+  }
+}
+
+template <typename T>
+__global__ void reshape_and_cache_fp8_generic_kernel(
+    const T* __restrict__ key, const T* __restrict__ value, uint8_t* __restrict__ key_cache,
+    uint8_t* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, int64_t key_stride,
+    int64_t value_stride, int num_heads, int head_size, int block_size, int x,
+    const float* __restrict__ k_scale, const float* __restrict__ v_scale) {
+  const int64_t token = blockIdx.x;
+  const int64_t slot = slot_mapping[token];
+  if (slot < 0) return;
+  const int64_t blk = slot / block_size;
+  const int64_t off = slot % block_size;
+  const float ks = *k_scale, vs = *v_scale;
+  const int n = num_heads * head_size;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int head = i / head_size;
+    const int ho = i % head_size;
+    const int xi = ho / x;
+    const int xo = ho % x;
+    const int64_t kdst = (((blk * num_heads + head) * (head_size / x) + xi) * block_size + off) * x + xo;
+    const int64_t vdst = ((blk * num_heads + head) * head_size + ho) * block_size + off;
+    key_cache[kdst] = f32_to_fp8_sat(to_f32(key[token * key_stride + i]) / ks);
+    value_cache[vdst] = f32_to_fp8_sat(to_f32(value[token * value_stride + i]) / vs);
+  }
+}
+
+template <typename T>
+__global__ void reshape_and_cache_flash_fp8_kernel(
+    const T* __restrict__ key, const T* __restrict__ value, uint8_t* __restrict__ key_cache,
+    uint8_t* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, int64_t block_stride,
+    int64_t page_stride, int64_t head_stride, int64_t key_stride, int64_t value_stride, int num_heads,
+    int head_size, int block_size, const float* __restrict__ k_scale,
+    const float* __restrict__ v_scale) {
+  const int64_t token = blockIdx.x;
+  const int64_t slot = slot_mapping[token];
+  if (slot < 0) return;
+  const int64_t blk = slot / block_size;
+  const int64_t off = slot % block_size;
+  const float ks = *k_scale, vs = *v_scale;
+  const T* ksrc = key + token * key_stride;
+  const T* vsrc = value + token * value_stride;
+  uint8_t* kdst = key_cache + blk * block_stride + off * page_stride;
+  uint8_t* vdst = value_cache + blk * block_stride + off * page_stride;
+  for (int i = threadIdx.x; i < num_heads * head_size; i += blockDim.x) {
+    const int head = i / head_size;
+    const int d = i - head * head_size;
+    const int64_t dof = (int64_t)head * head_stride + d;
+    kdst[dof] = f32_to_fp8_sat(to_f32(ksrc[i]) / ks);
+    vdst[dof] = f32_to_fp8_sat(to_f32(vsrc[i]) / vs);
+  }
+}
+
+// convert_fp8 (csrc/cache_kernels.cu:544-612, "only for testing" there): elementwise over the flat
+// cache, either direction.
+template <typename T, bool TO_FP8>
+__global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restrict__ src, float scale,
+                                   int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if constexpr (TO_FP8) {
+      static_cast<uint8_t*>(dst)[i] = f32_to_fp8_sat(to_f32(static_cast<const T*>(src)[i]) / scale);
+    } else {
+      static_cast<T*>(dst)[i] = from_f32<T>(fp8_to_f32(static_cast<const uint8_t*>(src)[i]) * scale);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // copy_blocks: layer pointers travel in the kernel argument (no H2D upload).
 constexpr int kCopyLayersPerLaunch = 64;
@@ -180,15 +320,44 @@ int mi355x_reshape_and_cache(const void* key, const void* value, void* key_cache
                              void* value_cache, const int64_t* slot_mapping,
                              int num_tokens, int64_t key_stride, int64_t value_stride,
                              int num_heads, int head_size, int block_size, int x,
-                             int dtype, mi355x_stream stream) {
+                             int dtype, int kv_cache_dtype, const float* k_scale,
+                             const float* v_scale, mi355x_stream stream) {
   MI355X_REQUIRE(num_tokens >= 0 && num_heads > 0 && head_size > 0 && block_size > 0 && x > 0,
                  MI355X_EINVAL, "reshape_and_cache: bad sizes");
+  MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3,
+                 MI355X_EUNSUPPORTED, "Unsupported data type of kv cache: id %d", kv_cache_dtype);
   MI355X_REQUIRE(head_size % x == 0, MI355X_EINVAL,
                  "reshape_and_cache: head_size %d not a multiple of x %d", head_size, x);
   if (num_tokens == 0) return MI355X_OK;
   MI355X_REQUIRE(key && value && key_cache && value_cache && slot_mapping, MI355X_EINVAL,
                  "reshape_and_cache: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (kv_cache_dtype == MI355X_KV_FP8_E4M3) {
+    MI355X_REQUIRE(k_scale && v_scale, MI355X_EINVAL, "reshape_and_cache: fp8 cache needs k_scale / v_scale");
+    return MI355X_DISPATCH_FLOAT(dtype, [&] {
+      constexpr int X = 16 / sizeof(scalar_t);
+      const scalar_t* k = static_cast<const scalar_t*>(key);
+      const scalar_t* v = static_cast<const scalar_t*>(value);
+      uint8_t* kc = static_cast<uint8_t*>(key_cache);
+      uint8_t* vc = static_cast<uint8_t*>(value_cache);
+      const bool vec = (x == 16) && (head_size % 16 == 0) && (key_stride % X == 0) &&
+                       (value_stride % X == 0) && aligned16(k) && aligned16(v) && aligned16(kc);
+      if (vec) {
+        dim3 grid((num_tokens + kTokTile - 1) / kTokTile, num_heads);
+        size_t smem = (size_t)kTokTile * (head_size + 16) + kTokTile * (sizeof(int64_t) + sizeof(int));
+        hipLaunchKernelGGL(reshape_and_cache_fp8_tiled_kernel<scalar_t>, grid, dim3(256), smem, s, k, v,
+                           kc, vc, slot_mapping, num_tokens, key_stride, value_stride, num_heads,
+                           head_size, block_size, k_scale, v_scale);
+      } else {
+        int threads = num_heads * head_size < 512 ? num_heads * head_size : 512;
+        threads = ((threads + 63) / 64) * 64;
+        hipLaunchKernelGGL(reshape_and_cache_fp8_generic_kernel<scalar_t>, dim3(num_tokens),
+                           dim3(threads), 0, s, k, v, kc, vc, slot_mapping, key_stride, value_stride,
+                           num_heads, head_size, block_size, x, k_scale, v_scale);
+      }
+      return check_launch("reshape_and_cache(fp8)");
+    });
+  }
   return MI355X_DISPATCH_FLOAT(dtype, [&] {
     constexpr int X = 16 / sizeof(scalar_t);
     const scalar_t* k = static_cast<const scalar_t*>(key);
@@ -221,13 +390,30 @@ int mi355x_reshape_and_cache_flash(const void* key, const void* value, void* key
                                    int64_t page_stride, int64_t head_stride,
                                    int64_t key_stride, int64_t value_stride,
                                    int num_heads, int head_size, int block_size,
-                                   int dtype, mi355x_stream stream) {
+                                   int dtype, int kv_cache_dtype, const float* k_scale,
+                                   const float* v_scale, mi355x_stream stream) {
   MI355X_REQUIRE(num_tokens >= 0 && num_heads > 0 && head_size > 0 && block_size > 0,
                  MI355X_EINVAL, "reshape_and_cache_flash: bad sizes");
+  MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3,
+                 MI355X_EUNSUPPORTED, "Unsupported data type of kv cache: id %d", kv_cache_dtype);
   if (num_tokens == 0) return MI355X_OK;
   MI355X_REQUIRE(key && value && key_cache && value_cache && slot_mapping, MI355X_EINVAL,
                  "reshape_and_cache_flash: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (kv_cache_dtype == MI355X_KV_FP8_E4M3) {
+    MI355X_REQUIRE(k_scale && v_scale, MI355X_EINVAL,
+                   "reshape_and_cache_flash: fp8 cache needs k_scale / v_scale");
+    return MI355X_DISPATCH_FLOAT(dtype, [&] {
+      int work = num_heads * head_size;
+      int threads = work < 256 ? ((work + 63) / 64) * 64 : 256;
+      hipLaunchKernelGGL(reshape_and_cache_flash_fp8_kernel<scalar_t>, dim3(num_tokens), dim3(threads),
+                         0, s, static_cast<const scalar_t*>(key), static_cast<const scalar_t*>(value),
+                         static_cast<uint8_t*>(key_cache), static_cast<uint8_t*>(value_cache),
+                         slot_mapping, block_stride, page_stride, head_stride, key_stride,
+                         value_stride, num_heads, head_size, block_size, k_scale, v_scale);
+      return check_launch("reshape_and_cache_flash(fp8)");
+    });
+  }
   return MI355X_DISPATCH_FLOAT(dtype, [&] {
     constexpr int X = 16 / sizeof(scalar_t);
     const scalar_t* k = static_cast<const scalar_t*>(key);
@@ -252,6 +438,25 @@ int mi355x_reshape_and_cache_flash(const void* key, const void* value, void* key
                          num_heads, head_size, block_size);
     }
     return check_launch("reshape_and_cache_flash");
+  });
+}
+
+int mi355x_convert_fp8(void* dst, const void* src, int64_t numel, float scale, int to_fp8,
+                       int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(numel >= 0, MI355X_EINVAL, "convert_fp8: bad size");
+  if (numel == 0) return MI355X_OK;
+  MI355X_REQUIRE(dst && src, MI355X_EINVAL, "convert_fp8: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int blocks = (int)((numel + 255) / 256 < 4096 ? (numel + 255) / 256 : 4096);
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    if (to_fp8) {
+      hipLaunchKernelGGL((convert_fp8_kernel<scalar_t, true>), dim3(blocks), dim3(256), 0, s, dst, src,
+                         scale, numel);
+    } else {
+      hipLaunchKernelGGL((convert_fp8_kernel<scalar_t, false>), dim3(blocks), dim3(256), 0, s, dst, src,
+                         scale, numel);
+    }
+    return check_launch("convert_fp8");
   });
 }
 

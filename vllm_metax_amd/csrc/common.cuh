@@ -201,6 +201,11 @@ __device__ __forceinline__ uint16_t f32x2_to_fp8x2_sat(float a, float b) {
   return static_cast<uint16_t>(packed & 0xffff);
 }
 
+// e4m3fn byte -> float (exact; v_cvt_f32_fp8)
+__device__ __forceinline__ float fp8_to_f32(uint8_t b) {
+  return __builtin_amdgcn_cvt_f32_fp8((int)b, 0);
+}
+
 // ---- split-K slab sum ------------------------------------------------------------
 // acc[j] = slab[0][j] + slab[1][j] + ... + slab[sk-1][j] in THAT order (the consumers of the
 // decode GEMM's fp32 partials must all round the same sum), V consecutive floats per lane.  The

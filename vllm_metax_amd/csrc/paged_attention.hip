@@ -24,6 +24,16 @@
 //     exactly the reference's rounding point.
 //   * reductions across the lanes that share a token are wave shuffles; across
 //     waves through LDS.
+//   * fp8 (e4m3fn) KV cache (kv_cache_dtype "fp8"; hook points of the reference:
+//     attention_kernels.cuh:86-89 cache_t, :266-277 / :398-407 scaled_convert; its dispatch rejects
+//     it, quant_utils.cuh:29-42 — semantics are upstream vLLM's): the cache holds bytes, x = 16, so
+//     a 16-B piece is 16 head elements of one token (K) / 16 tokens of one row (V).  A piece is
+//     converted ONCE to scalar_t in registers (exact: e4m3 is a subset of bf16 / f16 / f32) and
+//     then used for all GT query heads; k_scale is folded into the logit scale and v_scale into the
+//     output (upstream rounds T(byte * scale) per element first: identical for scale 1 and for
+//     powers of two, otherwise this form carries one rounding less).
+#include <type_traits>
+
 #include "common.cuh"
 
 namespace mi355x {
@@ -68,40 +78,110 @@ __device__ __forceinline__ float dot_chunk<float>(const uint4& a, const uint4& b
   return acc;
 }
 
-// zero the elements of a 16-B V piece whose token index is >= seq_len
+// 16 e4m3 bytes -> 16 scalar_t values (QP = 16 * sizeof(T) / 16 uint4s), exact.
 template <typename T>
+struct Fp8Piece;
+template <>
+struct Fp8Piece<bf16_t> {
+  static constexpr int QP = 2;
+  static __device__ __forceinline__ void cvt(const uint4& r, uint4 (&t)[2]) {
+    auto lo = [](uint32_t w) {
+      return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+    };
+    auto hi = [](uint32_t w) {
+      return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true));
+    };
+    t[0] = make_uint4(lo(r.x), hi(r.x), lo(r.y), hi(r.y));
+    t[1] = make_uint4(lo(r.z), hi(r.z), lo(r.w), hi(r.w));
+  }
+};
+template <>
+struct Fp8Piece<f16_t> {
+  static constexpr int QP = 2;
+  static __device__ __forceinline__ void cvt(const uint4& r, uint4 (&t)[2]) {
+    auto lo = [](uint32_t w) {
+      return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false));
+    };
+    auto hi = [](uint32_t w) {
+      return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true));
+    };
+    t[0] = make_uint4(lo(r.x), hi(r.x), lo(r.y), hi(r.y));
+    t[1] = make_uint4(lo(r.z), hi(r.z), lo(r.w), hi(r.w));
+  }
+};
+template <>
+struct Fp8Piece<float> {
+  static constexpr int QP = 4;
+  static __device__ __forceinline__ void cvt(const uint4& r, uint4 (&t)[4]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false);
+      const f32x2 b = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);
+      t[i] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x),
+                        __float_as_uint(b.y));
+    }
+  }
+};
+
+// One 16-B cache piece as scalar_t values: CT == T -> the piece itself; CT == uint8_t -> converted.
+template <typename T, typename CT>
+struct Piece {
+  static constexpr int QP = std::is_same<T, CT>::value ? 1 : Fp8Piece<T>::QP;
+  static __device__ __forceinline__ void cvt(const uint4& r, uint4 (&t)[QP]) {
+    if constexpr (std::is_same<T, CT>::value) t[0] = r;
+    else Fp8Piece<T>::cvt(r, t);
+  }
+  static __device__ __forceinline__ float dot(const uint4 (&a)[QP], const uint4 (&b)[QP], float acc) {
+#pragma unroll
+    for (int p = 0; p < QP; ++p) acc = dot_chunk<T>(a[p], b[p], acc);
+    return acc;
+  }
+};
+
+// zero the elements of a 16-B V piece whose token index is >= seq_len (a zero byte is +0 in e4m3)
+template <typename CT>
 __device__ __forceinline__ uint4 mask_tail(uint4 v, int first_token, int seq_len) {
-  constexpr int X = 16 / sizeof(T);
-  T e[X];
+  constexpr int X = 16 / sizeof(CT);
+  CT e[X];
   *reinterpret_cast<uint4*>(e) = v;
 #pragma unroll
   for (int j = 0; j < X; ++j) {
-    if (first_token + j >= seq_len) e[j] = from_f32<T>(0.f);
+    if (first_token + j >= seq_len) e[j] = CT(0);
   }
   return *reinterpret_cast<uint4*>(e);
 }
 
 // HS == 0: head size is a run-time value (any multiple of 16/sizeof(T) up to 256).
-template <typename T, int BS, int GT, int HS>
+// CT: element type of the cache (T, or uint8_t = e4m3fn bytes with x = 16).
+template <typename T, typename CT, int BS, int GT, int HS>
 __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
     float* __restrict__ exp_sums,    // [num_seqs, num_heads, P]       (partitioned only)
     float* __restrict__ max_logits,  // [num_seqs, num_heads, P]       (partitioned only)
     T* __restrict__ out,             // [num_seqs, num_heads, P, head_size]
     const T* __restrict__ q,         // [num_seqs, num_heads, head_size]
-    const T* __restrict__ k_cache,   // [num_blocks, num_kv_heads, head_size/x, BS, x]
-    const T* __restrict__ v_cache,   // [num_blocks, num_kv_heads, head_size, BS]
+    const CT* __restrict__ k_cache,  // [num_blocks, num_kv_heads, head_size/x, BS, x]
+    const CT* __restrict__ v_cache,  // [num_blocks, num_kv_heads, head_size, BS]
     int num_heads, int num_kv_heads, int head_size_rt, float scale,
     const int* __restrict__ block_tables, const int* __restrict__ seq_lens,
     int max_num_blocks_per_seq, const float* __restrict__ alibi_slopes, int64_t q_stride,
-    int64_t kv_block_stride, int64_t kv_head_stride, int partition_size, int logits_cap) {
-  constexpr int X = 16 / sizeof(T);
+    int64_t kv_block_stride, int64_t kv_head_stride, int partition_size, int logits_cap,
+    const float* __restrict__ k_scale, const float* __restrict__ v_scale) {
+  constexpr bool KV8 = !std::is_same<T, CT>::value;
+  constexpr int XT = 16 / sizeof(T);           // scalar_t elements per 16 B (q staging)
+  constexpr int X = 16 / sizeof(CT);           // cache elements per 16-B piece
+  constexpr int QP = Piece<T, CT>::QP;         // uint4s of scalar_t that one piece expands to
   constexpr int LPT = 64 / BS;                 // lanes that share one token in QK
   constexpr int TPP = BS / X;                  // 16-B pieces per V row
+  static_assert(TPP >= 1, "block_size must cover at least one 16-byte piece of the cache type");
   constexpr int DPI = 64 / TPP;                // V rows covered by one wave load
   const int D = HS ? HS : head_size_rt;
-  const int C = D / X;                         // 16-B chunks per head vector
+  const int C = D / X;                         // 16-B pieces per head vector in the cache
+  const int CQ = D / XT;                       // 16-B chunks of a query row
   constexpr int NI = HS ? (HS / X + LPT - 1) / LPT : 0;   // K pieces per lane per block
   constexpr int NIV = HS ? (HS + DPI - 1) / DPI : (256 + DPI - 1) / DPI;
+  if constexpr (KV8) scale *= *k_scale;        // logits = scale * k_scale * <q, K8>
 
   const int seq = blockIdx.y;
   const int part = blockIdx.z;
@@ -141,14 +221,14 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   T* probs = reinterpret_cast<T*>(logits + (size_t)GT * logits_cap);    // [GT][cap]
 
   // ---- stage q (packed scalar_t) into LDS; absent heads are zero ---------------
-  for (int i = tid; i < GT * C; i += nthreads) {
-    const int g = i / C;
-    const int c = i - g * C;
+  for (int i = tid; i < GT * CQ; i += nthreads) {
+    const int g = i / CQ;
+    const int c = i - g * CQ;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (g < nheads) {
-      v = *reinterpret_cast<const uint4*>(q + (int64_t)seq * q_stride + (int64_t)(head0 + g) * D + c * X);
+      v = *reinterpret_cast<const uint4*>(q + (int64_t)seq * q_stride + (int64_t)(head0 + g) * D + c * XT);
     }
-    *reinterpret_cast<uint4*>(q_s + g * D + c * X) = v;
+    *reinterpret_cast<uint4*>(q_s + g * D + c * XT) = v;
   }
   __syncthreads();
 
@@ -183,14 +263,17 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
 
   if constexpr (HS != 0) {
     // q chunks of this lane live in registers for the whole kernel
-    uint4 qreg[GT][NI];
+    uint4 qreg[GT][NI][QP];
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int c = csub + LPT * i;
-        qreg[g][i] = (c < C) ? *reinterpret_cast<const uint4*>(q_s + g * D + c * X)
-                             : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < QP; ++p) {
+          qreg[g][i][p] = (c < C) ? *reinterpret_cast<const uint4*>(q_s + g * D + c * X + p * XT)
+                                  : make_uint4(0, 0, 0, 0);
+        }
       }
     }
     // two blocks per iteration and wave -> 2*NI 16-B loads in flight per lane; the blocks that do
@@ -202,8 +285,8 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
       if (!work_item(it, blk, has2)) break;
       const int64_t pb0 = block_table[blk];
       const int64_t pb1 = has2 ? block_table[blk + 1] : pb0;
-      const T* kp0 = k_cache + pb0 * kv_block_stride + (int64_t)kv_head * kv_head_stride;
-      const T* kp1 = k_cache + pb1 * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+      const CT* kp0 = k_cache + pb0 * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+      const CT* kp1 = k_cache + pb1 * kv_block_stride + (int64_t)kv_head * kv_head_stride;
       uint4 k0[NI], k1[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
@@ -217,11 +300,20 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
       for (int g = 0; g < GT; ++g) {
         a0[g] = 0.f;
         a1[g] = 0.f;
+      }
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          a0[g] = dot_chunk<T>(k0[i], qreg[g][i], a0[g]);
-          a1[g] = dot_chunk<T>(k1[i], qreg[g][i], a1[g]);
+      for (int i = 0; i < NI; ++i) {
+        uint4 t0[QP], t1[QP];             // the piece as scalar_t (converted once, used by GT heads)
+        Piece<T, CT>::cvt(k0[i], t0);
+        Piece<T, CT>::cvt(k1[i], t1);
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+          a0[g] = Piece<T, CT>::dot(t0, qreg[g][i], a0[g]);
+          a1[g] = Piece<T, CT>::dot(t1, qreg[g][i], a1[g]);
         }
+      }
+#pragma unroll
+      for (int g = 0; g < GT; ++g) {
 #pragma unroll
         for (int m = BS; m < 64; m <<= 1) {
           a0[g] += __shfl_xor(a0[g], m, 64);
@@ -251,16 +343,20 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   } else {
     for (int blk = start_block + wave; blk < end_block; blk += nwaves) {
       const int64_t pb = block_table[blk];
-      const T* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+      const CT* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
       float a[GT];
 #pragma unroll
       for (int g = 0; g < GT; ++g) a[g] = 0.f;
       for (int c = csub; c < C; c += LPT) {
         const uint4 kv = *reinterpret_cast<const uint4*>(kp + (c * BS + t_in_blk) * X);
+        uint4 kt[QP];
+        Piece<T, CT>::cvt(kv, kt);
 #pragma unroll
         for (int g = 0; g < GT; ++g) {
-          const uint4 qv = *reinterpret_cast<const uint4*>(q_s + g * D + c * X);
-          a[g] = dot_chunk<T>(kv, qv, a[g]);
+          uint4 qv[QP];
+#pragma unroll
+          for (int p = 0; p < QP; ++p) qv[p] = *reinterpret_cast<const uint4*>(q_s + g * D + c * X + p * XT);
+          a[g] = Piece<T, CT>::dot(kt, qv, a[g]);
         }
       }
       const int tok = blk * BS + t_in_blk;
@@ -287,14 +383,14 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   const int dsub = lane / TPP0;   // V row phase
   auto load_v = [&](int blk, uint4 (&vv)[NIV]) {
     const int64_t pb = block_table[blk];
-    const T* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+    const CT* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
     const bool last = (blk == num_seq_blocks - 1);
 #pragma unroll
     for (int i = 0; i < NIV; ++i) {
       const int d = dsub + DPI0 * i;
       if (d < D) {
         uint4 v = *reinterpret_cast<const uint4*>(vp + (int64_t)d * BS + tq * X);
-        if (last) v = mask_tail<T>(v, blk * BS + tq * X, seq_len);
+        if (last) v = mask_tail<CT>(v, blk * BS + tq * X, seq_len);
         vv[i] = v;
       } else {
         vv[i] = make_uint4(0, 0, 0, 0);
@@ -360,15 +456,21 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   }
 
   auto pv_block = [&](int blk, const uint4 (&vv)[NIV]) {
-    uint4 pr[GT];
+    uint4 pr[GT][QP];
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
-      pr[g] = *reinterpret_cast<const uint4*>(probs + g * logits_cap + (blk - start_block) * BS + tq * X);
+#pragma unroll
+      for (int p = 0; p < QP; ++p) {
+        pr[g][p] = *reinterpret_cast<const uint4*>(probs + g * logits_cap + (blk - start_block) * BS +
+                                                   tq * X + p * XT);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NIV; ++i) {
+      uint4 vt[QP];
+      Piece<T, CT>::cvt(vv[i], vt);
 #pragma unroll
-      for (int g = 0; g < GT; ++g) oacc[g][i] = dot_chunk<T>(vv[i], pr[g], oacc[g][i]);
+      for (int g = 0; g < GT; ++g) oacc[g][i] = Piece<T, CT>::dot(vt, pr[g], oacc[g][i]);
     }
   };
 
@@ -424,13 +526,15 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
     }
   }
   __syncthreads();
+  float vs = 1.f;
+  if constexpr (KV8) vs = *v_scale;
   for (int i = tid; i < nheads * D; i += nthreads) {
     const int g = i / D;
     const int d = i - g * D;
     float acc = 0.f;
     for (int w = 0; w < nwaves; ++w) acc += osm[(w * GT + g) * D + d];
     const int64_t o = (((int64_t)seq * num_heads + head0 + g) * num_parts + part) * D + d;
-    out[o] = from_f32<T>(acc);
+    out[o] = from_f32<T>(KV8 ? acc * vs : acc);
   }
 }
 
@@ -496,12 +600,44 @@ struct PaArgs {
   int64_t q_stride, kv_block_stride, kv_head_stride;
   int partition_size;  // 0 => v1
   hipStream_t stream;
+  int kv_cache_dtype = MI355X_KV_AUTO;
+  const float* k_scale = nullptr;
+  const float* v_scale = nullptr;
 };
 
-template <typename T, int BS, int GT, int HS>
+// Launch geometry shared by the launcher and mi355x_paged_attention_v1_max_seq_len.
+struct PaPlan {
+  int gt, tiles, threads, logits_cap, num_parts;
+  size_t smem;
+};
+constexpr size_t kPaLdsLimit = 160 * 1024;
+
+static PaPlan pa_plan(int num_seqs, int num_heads, int num_kv_heads, int head_size, int block_size,
+                      int elt_size, int max_seq_len, int partition_size) {
+  PaPlan p;
+  const int q_per_kv = num_heads / num_kv_heads;
+  p.gt = q_per_kv >= 3 ? 4 : q_per_kv;  // 1, 2 or 4 heads per workgroup
+  p.tiles = (q_per_kv + p.gt - 1) / p.gt;
+  const int padded_len = ((max_seq_len + block_size - 1) / block_size) * block_size;
+  p.logits_cap = partition_size > 0 ? partition_size : padded_len;
+  p.num_parts = partition_size > 0 ? (max_seq_len + partition_size - 1) / partition_size : 1;
+  // Few workgroups (v1: one per (seq, kv head)) leave half of a CU's wave slots empty with
+  // 4-wave workgroups; 8 waves per workgroup put the same number of loads in flight per CU as the
+  // partitioned launch does (measured at 64 seqs x 8 kv heads, ctx 1088: see DESIGN.md §3).
+  const int64_t wgs = (int64_t)num_kv_heads * p.tiles * num_seqs * p.num_parts;
+  p.threads = wgs < 768 ? kPaMaxThreads : kPaThreads;
+  // the cross-wave output buffer [waves][GT][D] aliases the logits region
+  const int min_cap = (p.threads / 64) * head_size;
+  if (p.logits_cap < min_cap) p.logits_cap = min_cap;
+  p.logits_cap = (p.logits_cap + 63) & ~63;
+  p.smem = kPaScratchBytes + (size_t)p.gt * 256 * elt_size + (size_t)p.gt * p.logits_cap * (4 + elt_size);
+  return p;
+}
+
+template <typename T, typename CT, int BS, int GT, int HS>
 static int launch_pa_inst(const PaArgs& a, int tiles, int num_parts, int logits_cap,
                           size_t smem, int threads) {
-  auto kern = paged_attention_kernel<T, BS, GT, HS>;
+  auto kern = paged_attention_kernel<T, CT, BS, GT, HS>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -513,49 +649,32 @@ static int launch_pa_inst(const PaArgs& a, int tiles, int num_parts, int logits_
   dim3 grid(a.num_kv_heads * tiles, a.num_seqs, num_parts);
   T* dst = static_cast<T*>(a.partition_size > 0 ? a.tmp_out : a.out);
   hipLaunchKernelGGL(kern, grid, dim3(threads), smem, a.stream, a.exp_sums, a.max_logits, dst,
-                     static_cast<const T*>(a.query), static_cast<const T*>(a.key_cache),
-                     static_cast<const T*>(a.value_cache), a.num_heads, a.num_kv_heads,
+                     static_cast<const T*>(a.query), static_cast<const CT*>(a.key_cache),
+                     static_cast<const CT*>(a.value_cache), a.num_heads, a.num_kv_heads,
                      a.head_size, a.scale, a.block_tables, a.seq_lens,
                      a.max_num_blocks_per_seq, a.alibi_slopes, a.q_stride, a.kv_block_stride,
-                     a.kv_head_stride, a.partition_size, logits_cap);
+                     a.kv_head_stride, a.partition_size, logits_cap, a.k_scale, a.v_scale);
   return check_launch("paged_attention");
 }
 
-template <typename T, int BS>
+template <typename T, typename CT, int BS>
 static int launch_pa_bs(const PaArgs& a) {
-  constexpr int X = 16 / sizeof(T);
-  const int q_per_kv = a.num_heads / a.num_kv_heads;
-  const int gt = q_per_kv >= 3 ? 4 : q_per_kv;  // 1, 2 or 4 heads per workgroup
-  const int tiles = (q_per_kv + gt - 1) / gt;
-  const int padded_len = ((a.max_seq_len + BS - 1) / BS) * BS;
-  int logits_cap = a.partition_size > 0 ? a.partition_size : padded_len;
-  // the cross-wave output buffer [waves][GT][D] aliases the logits region
-  // Few workgroups (v1: one per (seq, kv head)) leave half of a CU's wave slots empty with
-  // 4-wave workgroups; 8 waves per workgroup put the same number of loads in flight per CU as the
-  // partitioned launch does (measured at 64 seqs x 8 kv heads, ctx 1088: see DESIGN.md §3).
-  const int num_parts_est =
-      a.partition_size > 0 ? (a.max_seq_len + a.partition_size - 1) / a.partition_size : 1;
-  const int64_t wgs = (int64_t)a.num_kv_heads * tiles * a.num_seqs * num_parts_est;
-  const int threads = wgs < 768 ? kPaMaxThreads : kPaThreads;
-  const int min_cap = (threads / 64) * a.head_size;
-  if (logits_cap < min_cap) logits_cap = min_cap;
-  logits_cap = (logits_cap + 63) & ~63;
-  const size_t smem = kPaScratchBytes + (size_t)gt * 256 * sizeof(T) +
-                      (size_t)gt * logits_cap * (4 + sizeof(T));
-  MI355X_REQUIRE(smem <= 160 * 1024, MI355X_EUNSUPPORTED,
+  const PaPlan p = pa_plan(a.num_seqs, a.num_heads, a.num_kv_heads, a.head_size, BS, (int)sizeof(T),
+                           a.max_seq_len, a.partition_size);
+  MI355X_REQUIRE(p.smem <= kPaLdsLimit, MI355X_EUNSUPPORTED,
                  "paged_attention_v1: max_seq_len %d needs %zu B of LDS (> 160 KiB); use "
-                 "paged_attention_v2",
-                 a.max_seq_len, smem);
-  const int num_parts =
-      a.partition_size > 0 ? (a.max_seq_len + a.partition_size - 1) / a.partition_size : 1;
+                 "paged_attention_v2 (mi355x_paged_attention_v1_max_seq_len gives the limit)",
+                 a.max_seq_len, p.smem);
   const bool fast = (a.head_size == 128) && (BS == 16) && (sizeof(T) == 2);
-#define PA_CASE(GTV)                                                                   \
-  if (gt == GTV) {                                                                     \
-    if (fast) {                                                                        \
-      if constexpr (BS == 16 && sizeof(T) == 2)                                        \
-        return launch_pa_inst<T, BS, GTV, 128>(a, tiles, num_parts, logits_cap, smem, threads); \
-    }                                                                                  \
-    return launch_pa_inst<T, BS, GTV, 0>(a, tiles, num_parts, logits_cap, smem, threads);       \
+#define PA_CASE(GTV)                                                                            \
+  if (p.gt == GTV) {                                                                            \
+    if (fast) {                                                                                 \
+      if constexpr (BS == 16 && sizeof(T) == 2)                                                 \
+        return launch_pa_inst<T, CT, BS, GTV, 128>(a, p.tiles, p.num_parts, p.logits_cap, p.smem, \
+                                                   p.threads);                                  \
+    }                                                                                           \
+    return launch_pa_inst<T, CT, BS, GTV, 0>(a, p.tiles, p.num_parts, p.logits_cap, p.smem,      \
+                                             p.threads);                                        \
   }
   PA_CASE(1)
   PA_CASE(2)
@@ -567,10 +686,19 @@ static int launch_pa_bs(const PaArgs& a) {
 
 template <typename T>
 static int launch_pa(const PaArgs& a) {
+  if (a.kv_cache_dtype == MI355X_KV_FP8_E4M3) {
+    switch (a.block_size) {   // a 16-byte piece of the byte cache is 16 tokens of a V row
+      case 16: return launch_pa_bs<T, uint8_t, 16>(a);
+      case 32: return launch_pa_bs<T, uint8_t, 32>(a);
+      default:
+        set_error("Unsupported block size with an fp8 KV cache: %d (16 or 32)", a.block_size);
+        return MI355X_EUNSUPPORTED;
+    }
+  }
   switch (a.block_size) {
-    case 8: return launch_pa_bs<T, 8>(a);
-    case 16: return launch_pa_bs<T, 16>(a);
-    case 32: return launch_pa_bs<T, 32>(a);
+    case 8: return launch_pa_bs<T, T, 8>(a);
+    case 16: return launch_pa_bs<T, T, 16>(a);
+    case 32: return launch_pa_bs<T, T, 32>(a);
     default:
       set_error("Unsupported block size: %d", a.block_size);
       return MI355X_EUNSUPPORTED;
@@ -595,6 +723,15 @@ static int validate_pa(const PaArgs& a, const char* name) {
                  MI355X_EINVAL, "%s: null pointer", name);
   MI355X_REQUIRE(a.num_seqs <= 65535, MI355X_EUNSUPPORTED, "%s: num_seqs %d > 65535", name,
                  a.num_seqs);
+  // ref: csrc/quantization/fp8/metax/quant_utils.cuh:29-42 rejects everything but "auto"; the
+  // e4m3 cache is this build's SURVEY §8f-3 row (upstream vLLM's "fp8" / "fp8_e4m3")
+  MI355X_REQUIRE(a.kv_cache_dtype == MI355X_KV_AUTO || a.kv_cache_dtype == MI355X_KV_FP8_E4M3,
+                 MI355X_EUNSUPPORTED, "Unsupported data type of kv cache: id %d", a.kv_cache_dtype);
+  if (a.kv_cache_dtype == MI355X_KV_FP8_E4M3) {
+    MI355X_REQUIRE(a.k_scale && a.v_scale, MI355X_EINVAL, "%s: fp8 KV cache needs k_scale / v_scale", name);
+    MI355X_REQUIRE(a.head_size % 16 == 0, MI355X_EUNSUPPORTED,
+                   "%s: fp8 KV cache needs head_size %% 16 == 0 (got %d)", name, a.head_size);
+  }
   return MI355X_OK;
 }
 
@@ -604,6 +741,22 @@ using namespace mi355x;
 
 extern "C" {
 
+int mi355x_paged_attention_v1_max_seq_len(int num_seqs, int num_heads, int num_kv_heads,
+                                          int head_size, int block_size, int dtype) {
+  MI355X_REQUIRE(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0 && head_size > 0 &&
+                     (block_size == 8 || block_size == 16 || block_size == 32),
+                 MI355X_EINVAL, "paged_attention_v1_max_seq_len: bad sizes");
+  MI355X_REQUIRE(dtype == MI355X_F16 || dtype == MI355X_BF16 || dtype == MI355X_F32, MI355X_EUNSUPPORTED,
+                 "unsupported dtype id %d", dtype);
+  const int esz = dtype_size(dtype);
+  const PaPlan p = pa_plan(num_seqs > 0 ? num_seqs : 1, num_heads, num_kv_heads, head_size, block_size,
+                           esz, block_size, 0);
+  const size_t fixed = kPaScratchBytes + (size_t)p.gt * 256 * esz;
+  int64_t cap = (int64_t)((kPaLdsLimit - fixed) / ((size_t)p.gt * (4 + esz)));
+  cap &= ~(int64_t)63;                       // the launcher rounds the logits capacity up to 64
+  return (int)cap;                           // = the largest max_seq_len whose padded length fits
+}
+
 int mi355x_paged_attention_v1(void* out, const void* query, const void* key_cache,
                               const void* value_cache, int num_seqs, int num_heads,
                               int num_kv_heads, int head_size, int block_size,
@@ -611,11 +764,12 @@ int mi355x_paged_attention_v1(void* out, const void* query, const void* key_cach
                               const int* seq_lens, int max_num_blocks_per_seq,
                               int max_seq_len, const float* alibi_slopes,
                               int64_t q_stride, int64_t kv_block_stride,
-                              int64_t kv_head_stride, int dtype, mi355x_stream stream) {
+                              int64_t kv_head_stride, int dtype, int kv_cache_dtype,
+                              const float* k_scale, const float* v_scale, mi355x_stream stream) {
   PaArgs a{out, nullptr, nullptr, nullptr, query, key_cache, value_cache, num_seqs, num_heads,
            num_kv_heads, head_size, block_size, scale, block_tables, seq_lens,
            max_num_blocks_per_seq, max_seq_len, alibi_slopes, q_stride, kv_block_stride,
-           kv_head_stride, 0, static_cast<hipStream_t>(stream)};
+           kv_head_stride, 0, static_cast<hipStream_t>(stream), kv_cache_dtype, k_scale, v_scale};
   int rc = validate_pa(a, "paged_attention_v1");
   if (rc || num_seqs == 0) return rc;
   return MI355X_DISPATCH_FLOAT(dtype, [&] { return launch_pa<scalar_t>(a); });
@@ -629,11 +783,13 @@ int mi355x_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
                               const int* seq_lens, int max_num_blocks_per_seq,
                               int max_seq_len, const float* alibi_slopes,
                               int64_t q_stride, int64_t kv_block_stride,
-                              int64_t kv_head_stride, int dtype, mi355x_stream stream) {
+                              int64_t kv_head_stride, int dtype, int kv_cache_dtype,
+                              const float* k_scale, const float* v_scale, mi355x_stream stream) {
   PaArgs a{out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs,
            num_heads, num_kv_heads, head_size, block_size, scale, block_tables, seq_lens,
            max_num_blocks_per_seq, max_seq_len, alibi_slopes, q_stride, kv_block_stride,
-           kv_head_stride, MI355X_PA_PARTITION_SIZE, static_cast<hipStream_t>(stream)};
+           kv_head_stride, MI355X_PA_PARTITION_SIZE, static_cast<hipStream_t>(stream),
+           kv_cache_dtype, k_scale, v_scale};
   int rc = validate_pa(a, "paged_attention_v2");
   if (rc || num_seqs == 0) return rc;
   MI355X_REQUIRE(exp_sums && max_logits && tmp_out, MI355X_EINVAL,

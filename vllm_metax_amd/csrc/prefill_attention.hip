@@ -22,6 +22,10 @@
 //     = 8*lr + j <-> key (block j>>2, 4*lr + (j&3))): probabilities never leave registers;
 //   * online softmax: every accumulator register of a lane belongs to the same query column,
 //     so the rescale factor is one scalar per lane and column tile.
+//   * fp8 (e4m3fn) KV cache (KV8): blocks are 2 KiB ([d/16][16][16] bytes / [d][16] bytes), copied
+//     verbatim as well; a lane's MFMA fragment is 8 bytes of K (ds_read_b64) or 4 + 4 bytes of V,
+//     converted exactly to scalar_t in registers (v_cvt_scalef32_pk_*_fp8, scale 1); k_scale is
+//     folded into the softmax scale and v_scale into the final 1/l.
 #include "common.cuh"
 
 namespace mi355x {
@@ -38,6 +42,12 @@ struct MfmaQK<bf16_t> {
     bf16x2_t v = {static_cast<bf16_t>(lo), static_cast<bf16_t>(hi)};
     return __builtin_bit_cast(uint32_t, v);
   }
+  // 4 e4m3 bytes -> 4 bf16 (two packed words), exact
+  static __device__ __forceinline__ uint2 from_fp8x4(uint32_t w) {
+    return make_uint2(
+        __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false)),
+        __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true)));
+  }
 };
 template <>
 struct MfmaQK<f16_t> {
@@ -48,6 +58,11 @@ struct MfmaQK<f16_t> {
   static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
     f16x2_t v = {static_cast<f16_t>(lo), static_cast<f16_t>(hi)};
     return __builtin_bit_cast(uint32_t, v);
+  }
+  static __device__ __forceinline__ uint2 from_fp8x4(uint32_t w) {
+    return make_uint2(
+        __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false)),
+        __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true)));
   }
 };
 
@@ -67,17 +82,24 @@ constexpr int kPfKvTile = 32;   // keys per stage (2 cache blocks)
 constexpr int kPfStages = 3;    // LDS ring depth (16 KiB per stage)
 constexpr float kNegBig = -1.0e30f;
 
-template <typename T>
+template <typename T, bool KV8>
 __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
-    T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k_cache,
-    const T* __restrict__ v_cache, int num_heads, int num_kv_heads, float scale,
+    T* __restrict__ out, const T* __restrict__ q, const void* __restrict__ k_cache_v,
+    const void* __restrict__ v_cache_v, int num_heads, int num_kv_heads, float scale,
     const int* __restrict__ block_tables, const int* __restrict__ seq_lens,
     const int* __restrict__ cu_seqlens_q, int max_num_blocks_per_seq, int q_blocks_per_seq,
-    int64_t q_stride, int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride) {
+    int64_t q_stride, int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+    const float* __restrict__ k_scale, const float* __restrict__ v_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [stage][K: 2 blocks x 4 KiB | V: 2 blocks x 4 KiB]
+  // [stage][K: 2 blocks | V: 2 blocks], a block = 4 KiB (scalar_t cache) or 2 KiB (fp8 cache)
   uint4* lds = reinterpret_cast<uint4*>(smem);
-  constexpr int kStageVec = 4 * 4096 / 16;  // uint4 per stage (16 KiB)
+  constexpr int kBlkBytes = KV8 ? 2048 : 4096;
+  constexpr int kStageVec = 4 * kBlkBytes / 16;  // uint4 per stage (16 / 8 KiB)
+  constexpr int kCopies = KV8 ? 2 : 4;           // 1-KiB DMA pieces per wave and stage
+  const char* k_cache = static_cast<const char*>(k_cache_v);   // strides below are in cache elements
+  const char* v_cache = static_cast<const char*>(v_cache_v);
+  constexpr int kCe = KV8 ? 1 : (int)sizeof(T);                // bytes per cache element
+  if constexpr (KV8) scale *= *k_scale;
 
   // heaviest query blocks first: under the causal mask block qb needs (qb + 1) * 4 key stages, and
   // workgroups are dispatched in blockIdx order — the long ones must not be the last to start
@@ -147,14 +169,32 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     return (int64_t)__builtin_amdgcn_readlane(bt_reg, blk - bt_base);
   };
   auto stage_issue = [&](int slot, int tile) {
+    if constexpr (!KV8) {
+      // wave w copies bytes [1024 w, 1024 w + 1024) of each of the four 4-KiB blocks
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int blk = tile * 2 + (i & 1);
-      blk = blk < num_seq_blocks ? blk : num_seq_blocks - 1;
-      const int64_t pb = block_id(blk);
-      const T* base = (i < 2 ? k_cache : v_cache) + pb * kv_block_stride +
-                      (int64_t)kv_head * kv_head_stride;
-      lds_dma16(base + wave * 512 + lane * 8, lds_base + slot * (kStageVec * 16) + i * 4096 + wave * 1024);
+      for (int i = 0; i < 4; ++i) {
+        int blk = tile * 2 + (i & 1);
+        blk = blk < num_seq_blocks ? blk : num_seq_blocks - 1;
+        const int64_t pb = block_id(blk);
+        const char* base = (i < 2 ? k_cache : v_cache) +
+                           (pb * kv_block_stride + (int64_t)kv_head * kv_head_stride) * kCe;
+        lds_dma16(base + wave * 1024 + lane * 16,
+                  lds_base + slot * (kStageVec * 16) + i * 4096 + wave * 1024);
+      }
+    } else {
+      // eight 1-KiB pieces [K0 lo, K0 hi, K1 lo, K1 hi, V0 lo, ...]; wave w copies pieces w and w + 4
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int piece = wave + 4 * i;
+        const int b = piece >> 1;                       // 0: K blk0, 1: K blk1, 2: V blk0, 3: V blk1
+        int blk = tile * 2 + (b & 1);
+        blk = blk < num_seq_blocks ? blk : num_seq_blocks - 1;
+        const int64_t pb = block_id(blk);
+        const char* base = (b < 2 ? k_cache : v_cache) +
+                           (pb * kv_block_stride + (int64_t)kv_head * kv_head_stride) * kCe;
+        lds_dma16(base + (piece & 1) * 1024 + lane * 16,
+                  lds_base + slot * (kStageVec * 16) + piece * 1024);
+      }
     }
   };
 
@@ -170,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
   int cur = 0;   // ring slot of `tile`
   for (int tile = 0; tile < num_tiles; ++tile) {
     // stage `tile` has landed once only the copies of the next stage are pending
-    if (tile + 1 < num_tiles) lds_dma_wait<4>();
+    if (tile + 1 < num_tiles) lds_dma_wait<kCopies>();
     else lds_dma_wait<0>();
     __syncthreads();   // everybody's share of stage `tile` is in LDS; stage tile-1 is dead
     if (tile + 2 < num_tiles) {
@@ -183,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     if (t0 <= wave_q_hi) {
       const uint4* kbuf = lds + cur * kStageVec;
       const uint2* vbuf = reinterpret_cast<const uint2*>(lds + cur * kStageVec + 512);
+      const char* sbuf = reinterpret_cast<const char*>(lds + cur * kStageVec);   // fp8 stage image
       // ---- S^T tiles: s[b][qt] = K_b . Q_qt^T, rows = keys 16*b + 4*lr + j, col = query lc
       f32x4_t s[2][2];
 #pragma unroll
@@ -191,7 +232,16 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
         for (int qt = 0; qt < 2; ++qt) s[b][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
-          const uint4 kf = kbuf[b * 256 + ds * 64 + lane];
+          uint4 kf;
+          if constexpr (!KV8) {
+            kf = kbuf[b * 256 + ds * 64 + lane];
+          } else {
+            // d = 32 ds + 8 lr + j -> piece 2 ds + (lr >> 1), bytes 8 (lr & 1) .. +7 of token lc
+            const uint2 raw = *reinterpret_cast<const uint2*>(
+                sbuf + b * 2048 + ((2 * ds + (lr >> 1)) * 16 + lc) * 16 + 8 * (lr & 1));
+            const uint2 lo = MfmaQK<T>::from_fp8x4(raw.x), hi = MfmaQK<T>::from_fp8x4(raw.y);
+            kf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          }
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) s[b][qt] = MfmaQK<T>::run(kf, qf[qt][ds], s[b][qt]);
         }
@@ -255,8 +305,16 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
         // V block image [128 d][16 keys]: row 16*dt + lc, keys 4*lr..4*lr+3 -> 8 bytes
-        uint2 v0 = vbuf[(0 * 4096 + (16 * dt + lc) * 32 + 8 * lr) / 8];
-        uint2 v1 = vbuf[(1 * 4096 + (16 * dt + lc) * 32 + 8 * lr) / 8];
+        uint2 v0, v1;
+        if constexpr (!KV8) {
+          v0 = vbuf[(0 * 4096 + (16 * dt + lc) * 32 + 8 * lr) / 8];
+          v1 = vbuf[(1 * 4096 + (16 * dt + lc) * 32 + 8 * lr) / 8];
+        } else {   // V block image [128 d][16 keys] bytes: row 16 dt + lc, keys 4 lr .. 4 lr + 3
+          v0 = MfmaQK<T>::from_fp8x4(*reinterpret_cast<const uint32_t*>(
+              sbuf + 4096 + (16 * dt + lc) * 16 + 4 * lr));
+          v1 = MfmaQK<T>::from_fp8x4(*reinterpret_cast<const uint32_t*>(
+              sbuf + 6144 + (16 * dt + lc) * 16 + 4 * lr));
+        }
         if (tail) {  // keys >= seq_len may hold NaN garbage: 0 * NaN must not reach O
           v0 = zero_tail4(v0, seq_len - (t0 + 4 * lr));
           v1 = zero_tail4(v1, seq_len - (t0 + 16 + 4 * lr));
@@ -275,7 +333,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     float l = lrun[qt];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
+    float inv = 1.0f / l;
+    if constexpr (KV8) inv *= *v_scale;
     if (qrow[qt] < q_len) {
       T* op = out + (int64_t)(q_begin + qrow[qt]) * out_stride + (int64_t)head * kPfD + 4 * lr;
 #pragma unroll
@@ -291,20 +350,31 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
 // ---------------------------------------------------------------------------------------
 // Generic fallback (any head size / block size / dtype): one wave per (query token, head),
 // lanes stride over keys, two passes (max+sum, then PV).  Correctness path only.
-template <typename T>
+template <typename CT>
+__device__ __forceinline__ float cache_to_f32(CT v) {
+  if constexpr (sizeof(CT) == 1) return fp8_to_f32((uint8_t)v);
+  else return to_f32(v);
+}
+
+template <typename T, typename CT>
 __global__ __launch_bounds__(64) void paged_prefill_generic_kernel(
-    T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k_cache,
-    const T* __restrict__ v_cache, int num_heads, int num_kv_heads, int head_size,
+    T* __restrict__ out, const T* __restrict__ q, const CT* __restrict__ k_cache,
+    const CT* __restrict__ v_cache, int num_heads, int num_kv_heads, int head_size,
     int block_size, float scale, const int* __restrict__ block_tables,
     const int* __restrict__ seq_lens, const int* __restrict__ cu_seqlens_q, int num_seqs,
     int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
-    int64_t kv_head_stride) {
+    int64_t kv_head_stride, const float* __restrict__ k_scale, const float* __restrict__ v_scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* qs = reinterpret_cast<float*>(smem);  // [head_size]
   const int tok = blockIdx.x;
   const int head = blockIdx.y;
   const int lane = threadIdx.x;
-  constexpr int X = 16 / sizeof(T);
+  constexpr int X = 16 / sizeof(CT);
+  float vsc = 1.f;
+  if constexpr (sizeof(CT) == 1 && sizeof(T) != 1) {
+    scale *= *k_scale;
+    vsc = *v_scale;
+  }
   // locate the sequence of this token (num_seqs is small; linear scan)
   int seq = 0;
   while (seq + 1 < num_seqs && cu_seqlens_q[seq + 1] <= tok) ++seq;
@@ -322,10 +392,10 @@ __global__ __launch_bounds__(64) void paged_prefill_generic_kernel(
   auto kdot = [&](int key) {
     const int64_t pb = block_table[key / block_size];
     const int off = key % block_size;
-    const T* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+    const CT* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
     float acc = 0.f;
     for (int d = 0; d < head_size; ++d) {
-      acc += qs[d] * to_f32(kp[((d / X) * block_size + off) * X + (d % X)]);
+      acc += qs[d] * cache_to_f32<CT>(kp[((d / X) * block_size + off) * X + (d % X)]);
     }
     return acc * scale;
   };
@@ -342,11 +412,11 @@ __global__ __launch_bounds__(64) void paged_prefill_generic_kernel(
     for (int key = 0; key < visible; ++key) {
       const int64_t pb = block_table[key / block_size];
       const int off = key % block_size;
-      const T* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+      const CT* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
       const float p = to_f32(from_f32<T>(__expf(kdot(key) - m) * inv));
-      acc += p * to_f32(vp[(int64_t)d * block_size + off]);
+      acc += p * cache_to_f32<CT>(vp[(int64_t)d * block_size + off]);
     }
-    out[(int64_t)tok * out_stride + (int64_t)head * head_size + d] = from_f32<T>(acc);
+    out[(int64_t)tok * out_stride + (int64_t)head * head_size + d] = from_f32<T>(acc * vsc);
   }
 }
 
@@ -359,7 +429,15 @@ extern "C" int mi355x_paged_prefill_attention(
     int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
     const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
     int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
-    int64_t kv_head_stride, int dtype, mi355x_stream stream) {
+    int64_t kv_head_stride, int dtype, int kv_cache_dtype, const float* k_scale,
+    const float* v_scale, mi355x_stream stream) {
+  MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3,
+                 MI355X_EUNSUPPORTED, "Unsupported data type of kv cache: id %d", kv_cache_dtype);
+  const bool kv8 = kv_cache_dtype == MI355X_KV_FP8_E4M3;
+  MI355X_REQUIRE(!kv8 || (k_scale && v_scale), MI355X_EINVAL,
+                 "paged_prefill_attention: fp8 KV cache needs k_scale / v_scale");
+  MI355X_REQUIRE(!kv8 || head_size % 16 == 0, MI355X_EUNSUPPORTED,
+                 "paged_prefill_attention: fp8 KV cache needs head_size %% 16 == 0");
   MI355X_REQUIRE(num_seqs >= 0 && num_heads > 0 && num_kv_heads > 0 && head_size > 0 &&
                      block_size > 0 && max_query_len >= 0,
                  MI355X_EINVAL, "paged_prefill_attention: bad sizes");
@@ -374,19 +452,26 @@ extern "C" int mi355x_paged_prefill_attention(
                     q_stride % 8 == 0 && out_stride % 4 == 0 &&
                     ((reinterpret_cast<uintptr_t>(query) | reinterpret_cast<uintptr_t>(key_cache) |
                       reinterpret_cast<uintptr_t>(value_cache)) & 15) == 0 &&
-                    (reinterpret_cast<uintptr_t>(out) & 7) == 0 && kv_block_stride % 8 == 0 &&
-                    kv_head_stride % 8 == 0;
+                    (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
+                    kv_block_stride % (kv8 ? 16 : 8) == 0 && kv_head_stride % (kv8 ? 16 : 8) == 0;
   if (fast) {
     const int q_blocks = (max_query_len + kPfQTile - 1) / kPfQTile;
     dim3 grid(num_seqs * q_blocks * num_heads), block(256);
-    const size_t smem = (size_t)kPfStages * 4 * 4096;   // ring of 16-KiB stages
+    const size_t smem = (size_t)kPfStages * 4 * (kv8 ? 2048 : 4096);   // ring of 16- / 8-KiB stages
     return MI355X_DISPATCH_HALF(dtype, [&] {
-      hipLaunchKernelGGL(paged_prefill_d128_kernel<scalar_t>, grid, block, smem, s,
-                         static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query),
-                         static_cast<const scalar_t*>(key_cache),
-                         static_cast<const scalar_t*>(value_cache), num_heads, num_kv_heads, scale,
-                         block_tables, seq_lens, cu_seqlens_q, max_num_blocks_per_seq, q_blocks,
-                         q_stride, out_stride, kv_block_stride, kv_head_stride);
+      if (kv8) {
+        hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true>), grid, block, smem, s,
+                           static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
+                           value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
+                           cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
+                           kv_block_stride, kv_head_stride, k_scale, v_scale);
+      } else {
+        hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, false>), grid, block, smem, s,
+                           static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
+                           value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
+                           cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
+                           kv_block_stride, kv_head_stride, k_scale, v_scale);
+      }
       return check_launch("paged_prefill_attention");
     });
   }
@@ -395,13 +480,23 @@ extern "C" int mi355x_paged_prefill_attention(
   MI355X_REQUIRE(max_tokens <= 0x7fffffff, MI355X_EUNSUPPORTED, "paged_prefill_attention: too many tokens");
   dim3 grid((int)max_tokens, num_heads), block(64);
   return MI355X_DISPATCH_FLOAT(dtype, [&] {
-    hipLaunchKernelGGL(paged_prefill_generic_kernel<scalar_t>, grid, block,
-                       (size_t)head_size * sizeof(float), s, static_cast<scalar_t*>(out),
-                       static_cast<const scalar_t*>(query), static_cast<const scalar_t*>(key_cache),
-                       static_cast<const scalar_t*>(value_cache), num_heads, num_kv_heads, head_size,
-                       block_size, scale, block_tables, seq_lens, cu_seqlens_q, num_seqs,
-                       max_num_blocks_per_seq, q_stride, out_stride, kv_block_stride,
-                       kv_head_stride);
+    if (kv8) {
+      hipLaunchKernelGGL((paged_prefill_generic_kernel<scalar_t, uint8_t>), grid, block,
+                         (size_t)head_size * sizeof(float), s, static_cast<scalar_t*>(out),
+                         static_cast<const scalar_t*>(query), static_cast<const uint8_t*>(key_cache),
+                         static_cast<const uint8_t*>(value_cache), num_heads, num_kv_heads, head_size,
+                         block_size, scale, block_tables, seq_lens, cu_seqlens_q, num_seqs,
+                         max_num_blocks_per_seq, q_stride, out_stride, kv_block_stride,
+                         kv_head_stride, k_scale, v_scale);
+    } else {
+      hipLaunchKernelGGL((paged_prefill_generic_kernel<scalar_t, scalar_t>), grid, block,
+                         (size_t)head_size * sizeof(float), s, static_cast<scalar_t*>(out),
+                         static_cast<const scalar_t*>(query), static_cast<const scalar_t*>(key_cache),
+                         static_cast<const scalar_t*>(value_cache), num_heads, num_kv_heads, head_size,
+                         block_size, scale, block_tables, seq_lens, cu_seqlens_q, num_seqs,
+                         max_num_blocks_per_seq, q_stride, out_stride, kv_block_stride,
+                         kv_head_stride, k_scale, v_scale);
+    }
     return check_launch("paged_prefill_attention(generic)");
   });
 }

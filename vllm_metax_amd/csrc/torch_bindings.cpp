@@ -52,9 +52,21 @@ inline const T* cptr(const std::optional<Tensor>& t) {
                                                             : nullptr;
 }
 
-inline void check_kv_dtype(const std::string& s) {
-  // ref: csrc/quantization/fp8/metax/quant_utils.cuh:29-42
-  TORCH_CHECK(s == "auto", "Unsupported data type of kv cache: ", s);
+// `str kv_cache_dtype` -> mi355x_kv_cache_dtype.  The reference accepts only "auto"
+// (csrc/quantization/fp8/metax/quant_utils.cuh:29-42); "fp8" / "fp8_e4m3" (upstream's names) select
+// the e4m3fn cache of SURVEY §8f-3.
+inline int kv_dtype(const std::string& s, const Tensor& cache, const Tensor& k_scale,
+                    const Tensor& v_scale) {
+  if (s == "auto") return MI355X_KV_AUTO;
+  TORCH_CHECK(s == "fp8" || s == "fp8_e4m3", "Unsupported data type of kv cache: ", s);
+  TORCH_CHECK(cache.element_size() == 1, "kv_cache_dtype ", s, " needs a 1-byte cache tensor");
+  TORCH_CHECK(k_scale.is_cuda() && v_scale.is_cuda() && k_scale.scalar_type() == at::kFloat &&
+                  v_scale.scalar_type() == at::kFloat && k_scale.numel() == 1 && v_scale.numel() == 1,
+              "k_scale / v_scale must be one float32 element each on the GPU");
+  return MI355X_KV_FP8_E4M3;
+}
+inline const float* scale_ptr(int kvd, const Tensor& t) {
+  return kvd == MI355X_KV_AUTO ? nullptr : t.data_ptr<float>();
 }
 
 // ------------------------------------------------------------------- attention
@@ -66,7 +78,7 @@ void paged_attention_v1(Tensor& out, Tensor& query, Tensor& key_cache, Tensor& v
                         int64_t tp_rank, int64_t blocksparse_local_blocks,
                         int64_t blocksparse_vert_stride, int64_t blocksparse_block_size,
                         int64_t blocksparse_head_sliding_step) {
-  check_kv_dtype(kv_cache_dtype);
+  const int kvd = kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale);
   TORCH_CHECK(blocksparse_vert_stride <= 1, "block-sparse paged attention is not supported");
   Guard g(query);
   ok(mi355x_paged_attention_v1(
@@ -74,7 +86,8 @@ void paged_attention_v1(Tensor& out, Tensor& query, Tensor& key_cache, Tensor& v
          query.size(0), query.size(1), num_kv_heads, query.size(2), block_size, (float)scale,
          block_tables.data_ptr<int>(), seq_lens.data_ptr<int>(), block_tables.size(1),
          max_seq_len, cptr<float>(alibi_slopes), query.stride(0), key_cache.stride(0),
-         key_cache.stride(1), dt(query), stream_of(query)),
+         key_cache.stride(1), dt(query), kvd, scale_ptr(kvd, k_scale), scale_ptr(kvd, v_scale),
+         stream_of(query)),
      "paged_attention_v1");
 }
 
@@ -87,7 +100,7 @@ void paged_attention_v2(Tensor& out, Tensor& exp_sums, Tensor& max_logits, Tenso
                         int64_t tp_rank, int64_t blocksparse_local_blocks,
                         int64_t blocksparse_vert_stride, int64_t blocksparse_block_size,
                         int64_t blocksparse_head_sliding_step) {
-  check_kv_dtype(kv_cache_dtype);
+  const int kvd = kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale);
   TORCH_CHECK(blocksparse_vert_stride <= 1, "block-sparse paged attention is not supported");
   Guard g(query);
   ok(mi355x_paged_attention_v2(
@@ -96,7 +109,8 @@ void paged_attention_v2(Tensor& out, Tensor& exp_sums, Tensor& max_logits, Tenso
          query.size(0), query.size(1), num_kv_heads, query.size(2), block_size, (float)scale,
          block_tables.data_ptr<int>(), seq_lens.data_ptr<int>(), block_tables.size(1),
          max_seq_len, cptr<float>(alibi_slopes), query.stride(0), key_cache.stride(0),
-         key_cache.stride(1), dt(query), stream_of(query)),
+         key_cache.stride(1), dt(query), kvd, scale_ptr(kvd, k_scale), scale_ptr(kvd, v_scale),
+         stream_of(query)),
      "paged_attention_v2");
 }
 
@@ -502,28 +516,49 @@ void copy_blocks(std::vector<Tensor> const& key_caches, std::vector<Tensor> cons
 void reshape_and_cache(Tensor& key, Tensor& value, Tensor& key_cache, Tensor& value_cache,
                        Tensor& slot_mapping, const std::string& kv_cache_dtype, Tensor& k_scale,
                        Tensor& v_scale) {
-  check_kv_dtype(kv_cache_dtype);
+  const int kvd = kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale);
   Guard g(key);
   ok(mi355x_reshape_and_cache(key.data_ptr(), value.data_ptr(), key_cache.data_ptr(),
                               value_cache.data_ptr(), slot_mapping.data_ptr<int64_t>(),
                               slot_mapping.size(0), key.stride(0), value.stride(0), key.size(1),
-                              key.size(2), key_cache.size(3), key_cache.size(4), dt(key),
-                              stream_of(key)),
+                              key.size(2), key_cache.size(3), key_cache.size(4), dt(key), kvd,
+                              scale_ptr(kvd, k_scale), scale_ptr(kvd, v_scale), stream_of(key)),
      "reshape_and_cache");
 }
 
 void reshape_and_cache_flash(Tensor& key, Tensor& value, Tensor& key_cache, Tensor& value_cache,
                              Tensor& slot_mapping, const std::string& kv_cache_dtype,
                              Tensor& k_scale, Tensor& v_scale) {
-  check_kv_dtype(kv_cache_dtype);
+  const int kvd = kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale);
   TORCH_CHECK(key_cache.stride(0) == value_cache.stride(0));
   Guard g(key);
   ok(mi355x_reshape_and_cache_flash(
          key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
          slot_mapping.data_ptr<int64_t>(), slot_mapping.size(0), key_cache.stride(0),
          key_cache.stride(1), key_cache.stride(2), key.stride(0), value.stride(0), key.size(1),
-         key.size(2), key_cache.size(1), dt(key), stream_of(key)),
+         key.size(2), key_cache.size(1), dt(key), kvd, scale_ptr(kvd, k_scale),
+         scale_ptr(kvd, v_scale), stream_of(key)),
      "reshape_and_cache_flash");
+}
+
+// ref: csrc/cache_kernels.cu:564-612 ("Only for testing" there)
+void convert_fp8(Tensor& dst_cache, Tensor& src_cache, double scale, const std::string& kv_cache_dtype) {
+  TORCH_CHECK(src_cache.is_cuda(), "src must be on a GPU");
+  TORCH_CHECK(dst_cache.is_cuda(), "dst must be on a GPU");
+  TORCH_CHECK(src_cache.get_device() == dst_cache.get_device(), "src and dst must be on the same GPU");
+  TORCH_CHECK(kv_cache_dtype == "fp8" || kv_cache_dtype == "fp8_e4m3", "Unsupported data type: ",
+              kv_cache_dtype);
+  TORCH_CHECK(src_cache.numel() == dst_cache.numel() && src_cache.is_contiguous() &&
+                  dst_cache.is_contiguous(),
+              "convert_fp8: contiguous tensors of equal size expected");
+  const bool to_fp8 = dst_cache.element_size() == 1;
+  TORCH_CHECK((to_fp8 ? src_cache : dst_cache).element_size() != 1 &&
+                  (to_fp8 ? dst_cache : src_cache).element_size() == 1,
+              "convert_fp8: exactly one side must be a 1-byte (fp8) tensor");
+  Guard g(src_cache);
+  ok(mi355x_convert_fp8(dst_cache.data_ptr(), src_cache.data_ptr(), src_cache.numel(), (float)scale,
+                        to_fp8 ? 1 : 0, dt(to_fp8 ? src_cache : dst_cache), stream_of(src_cache)),
+     "convert_fp8");
 }
 
 // ------------------------------------------------------------------ cuda utils
@@ -702,6 +737,11 @@ TORCH_LIBRARY(_C_cache_ops, cache_ops) {
       "                        str kv_cache_dtype,"
       "                        Tensor k_scale, Tensor v_scale) -> ()");
   cache_ops.impl("reshape_and_cache_flash", c10::kCUDA, &reshape_and_cache_flash);
+
+  cache_ops.def(
+      "convert_fp8(Tensor! dst_cache, Tensor src_cache, float scale, "
+      "str kv_cache_dtype) -> ()");
+  cache_ops.impl("convert_fp8", c10::kCUDA, &convert_fp8);
 }
 
 TORCH_LIBRARY(_C_cuda_utils, cuda_utils) {

@@ -399,8 +399,86 @@ static int launch_small_m(const GemmArgs& g, int row0, int rows) {
   return rc;
 }
 
+
+// ------------------------------------------------------------------ any-N fallback
+// Shapes the tiled kernels do not take (n % 64 != 0; the reference only asks n % 16 == 0,
+// gemm_kernels.cu:194-201): one workgroup = 16 columns x 8 rows, 16 k-parts of one lane each,
+// weights dequantised with the same exact formula, fp32 accumulation, LDS tree over the k-parts.
+// Correctness path (tiny test shapes), not a performance kernel.
+template <typename T, int ZMODE>
+__global__ __launch_bounds__(256) void w4a16_gemm_any_n_kernel(
+    T* __restrict__ c, const T* __restrict__ a, const uint32_t* __restrict__ qw,
+    const T* __restrict__ scales, const uint32_t* __restrict__ qz, int m, int n, int k, int group,
+    int64_t lda) {
+  __shared__ float red[16][8][17];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int kp = threadIdx.x >> 4;           // k-part 0..15
+  const int row0 = blockIdx.y * 8;
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+  if (col < n) {
+    for (int kk = kp; kk < k / 8; kk += 16) {
+      const int g = (kk * 8) / group;
+      const uint32_t w = qw[(int64_t)kk * n + col];
+      const float s = to_f32(scales[(int64_t)g * n + col]);
+      float z;
+      if constexpr (ZMODE == kZeroAwq) {
+        z = (float)((qz[(int64_t)g * (n >> 3) + (col >> 3)] >> (4 * awq_shift(col & 7))) & 0xFu);
+      } else {
+        z = (float)(((qz[(int64_t)g * (n >> 3) + (col >> 3)] >> (4 * (col & 7))) & 0xFu) + 1u);
+      }
+      float wv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {   // k row 8kk + j sits at nibble awq_shift(j)
+        const float q = (float)((w >> (4 * awq_shift(j))) & 0xFu);
+        wv[j] = to_f32(from_f32<T>(fmaf(q, s, -z * s)));
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (row0 + r < m) {
+          const T* ap = a + (int64_t)(row0 + r) * lda + kk * 8;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[r] = fmaf(to_f32(ap[j]), wv[j], acc[r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) red[kp][r][threadIdx.x & 15] = acc[r];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int r = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    float sum = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) sum += red[p][r][cc];
+    const int oc = blockIdx.x * 16 + cc;
+    if (row0 + r < m && oc < n) c[(int64_t)(row0 + r) * n + oc] = from_f32<T>(sum);
+  }
+}
+
+template <typename T>
+static int launch_any_n(const GemmArgs& g) {
+  dim3 grid((g.n + 15) / 16, (g.m + 7) / 8), block(256);
+  if (g.zmode == kZeroAwq) {
+    hipLaunchKernelGGL((w4a16_gemm_any_n_kernel<T, kZeroAwq>), grid, block, 0, g.stream,
+                       static_cast<T*>(g.c), static_cast<const T*>(g.a), g.qw,
+                       static_cast<const T*>(g.scales), g.qz, g.m, g.n, g.k, g.group, g.lda);
+  } else {
+    hipLaunchKernelGGL((w4a16_gemm_any_n_kernel<T, kZeroGptq>), grid, block, 0, g.stream,
+                       static_cast<T*>(g.c), static_cast<const T*>(g.a), g.qw,
+                       static_cast<const T*>(g.scales), g.qz, g.m, g.n, g.k, g.group, g.lda);
+  }
+  return check_launch("w4a16_gemm_any_n");
+}
+
 template <typename T>
 static int run_gemm_t(const GemmArgs& g, int dtype) {
+  if (g.n % 64 != 0) {
+    MI355X_REQUIRE(g.defer_sk == nullptr && !g.fuse_silu && !g.a_packed, MI355X_EUNSUPPORTED,
+                   "w4a16 gemm: the fused / deferred forms need n %% 64 == 0 (n = %d)", g.n);
+    return launch_any_n<T>(g);
+  }
   if (g.m >= 1024) {
     int rc = w4a16_gemm_unfused_dispatch(g, dtype);
     if (rc != 1) return rc;  // 1 = no scratch / shape not handled: fall through to the fused kernel
@@ -425,7 +503,8 @@ static int run_gemm_t(const GemmArgs& g, int dtype) {
 
 static int validate_gemm(const GemmArgs& g, const char* name) {
   MI355X_REQUIRE(g.m >= 0 && g.n > 0 && g.k > 0 && g.group > 0, MI355X_EINVAL, "%s: bad sizes", name);
-  MI355X_REQUIRE(g.n % 64 == 0, MI355X_EUNSUPPORTED, "%s: n = %d must be a multiple of 64", name, g.n);
+  // the reference asks n % 16 == 0, k % 32 == 0 (gemm_kernels.cu:194-201); n % 64 != 0 runs a fallback
+  MI355X_REQUIRE(g.n % 8 == 0, MI355X_EUNSUPPORTED, "%s: n = %d must be a multiple of 8", name, g.n);
   MI355X_REQUIRE(g.k % 32 == 0, MI355X_EUNSUPPORTED, "%s: k = %d must be a multiple of 32", name, g.k);
   MI355X_REQUIRE(g.group % 32 == 0 && g.k % g.group == 0, MI355X_EUNSUPPORTED,
                  "%s: group_size %d must be a multiple of 32 that divides k", name, g.group);
