@@ -11,14 +11,17 @@ through the C-ABI HIP library; decode steps are replayed from a HIP graph.
 
     value = K * 64 * 128 output tokens / wall time of K jobs (inputs resident in HBM).
 
-`--gpus N` (launched by torch.distributed.run, one rank per GPU, RCCL for the rendezvous, the
-barriers and the max-over-ranks clock).  Sequences are independent units of this path, so the
-default `--parallelism dp` runs one model replica per GPU, each serving its own batch of 64
-prompts with no data-path collective: per-GPU work is fixed -> "scaling": "weak", value = the
-tokens ALL ranks produced / max-over-ranks time.  `--parallelism tp` instead shards ONE job with
-tensor parallelism TP=N (heads / FFN sharded, RCCL all-reduce after o_proj and down_proj,
-all-gather of the vocab-parallel logits): total work fixed -> "scaling": "strong" — the layout the
-70B/72B configs need; for an 8B model the decode GEMMs of a 1/8 shard are launch-bound.
+`--gpus N` (one rank per GPU: launched by torch.distributed.run, or — when WORLD_SIZE is not set —
+bench.py starts the N ranks itself as child processes; RCCL for the rendezvous, the collectives,
+the barriers and the max-over-ranks clock).  For N > 1 the measured mode is the one north_star
+names: TENSOR PARALLELISM TP=N over RCCL (`--parallelism tp`, the default for N > 1): ONE job of 64
+prompts, every layer sharded Megatron-style (q/kv heads and FFN columns per rank, RCCL all-reduce of
+the [M, hidden] bf16 activations after the row-parallel o_proj and down_proj, all-gather of the
+vocab-parallel logits), the decode step INCLUDING its collectives replayed from one HIP graph: total
+work fixed -> "scaling": "strong", value = output tokens of the job / max-over-ranks time.  The same
+run then also times the collective-free alternative — one model replica per GPU, each serving its
+own 64 prompts (`dp`, weak scaling) — and reports it as the extra object "dp_replicas"; `--parallelism
+dp` makes that the headline instead.
 
 Extra objects on the JSON line: "roofline" (dominant kernel, timed live with HIP events on
 the launch stream inside the timed region), "roofline_other" (the other hot kernels),
@@ -58,11 +61,15 @@ def parse_args():
     ap.add_argument("--input-len", type=int, default=1024)
     ap.add_argument("--output-len", type=int, default=128)
     ap.add_argument("--chunk-seqs", type=int, default=8)
-    ap.add_argument("--parallelism", default="dp", choices=["dp", "tp"],
-                    help="N > 1: dp = one model replica per GPU, each serving its own batch of "
-                         "--batch sequences (sequences are independent: no data-path collective, weak "
-                         "scaling); tp = one model sharded over the N GPUs (column/row-parallel GEMMs, "
-                         "RCCL all-reduce after o_proj / down_proj, strong scaling)")
+    ap.add_argument("--parallelism", default=None, choices=["dp", "tp"],
+                    help="N > 1: tp (default) = one model sharded over the N GPUs (column/row-parallel "
+                         "GEMMs, RCCL all-reduce after o_proj / down_proj, strong scaling); dp = one model "
+                         "replica per GPU, each serving its own batch of --batch sequences (no data-path "
+                         "collective, weak scaling)")
+    ap.add_argument("--no-dp-extra", action="store_true",
+                    help="tp runs: skip the additional dp-replica measurement (the \"dp_replicas\" object)")
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8"],
+                    help="fp8: e4m3 KV cache (SURVEY §8f-3), halves the bytes decode attention streams")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--kernel-stats", action="store_true",
@@ -150,19 +157,19 @@ def instrument(model, timer: EventTimer):
             return timer.time(opname, flops, nbytes, lambda: fn(*a, **k))
         setattr(ops, opname, w)
 
-    def cost_prefill(out, q, kc, vc, kvh, scale, bt, sl, cu, max_q, bs):
+    def cost_prefill(out, q, kc, vc, kvh, scale, bt, sl, cu, max_q, bs, *a, **k):
         T, H, D = q.shape
         n = sl.numel()
         ql = T // n
         L = int(model.cfg_ctx_for_cost) + ql
         flops = 4.0 * n * ql * (L - ql / 2.0) * H * D
-        nbytes = 2.0 * T * H * D * 2 + n * L * kvh * D * 2 * 2
+        nbytes = 2.0 * T * H * D * 2 + n * L * kvh * D * 2 * kc.element_size()
         return flops, nbytes
 
     def cost_decode(out, es, ml, tmp, q, kc, vc, kvh, scale, bt, sl, bs, max_len, *a, **k):
         S, H, D = q.shape
         mean_len = model.mean_decode_len_for_cost
-        nbytes = S * mean_len * kvh * D * 2 * 2 + 2.0 * S * H * D * 2
+        nbytes = S * mean_len * kvh * D * 2 * kc.element_size() + 2.0 * S * H * D * 2
         return 4.0 * S * mean_len * H * D, nbytes
 
     def cost_rows(n_reads, n_writes):
@@ -182,7 +189,7 @@ def instrument(model, timer: EventTimer):
     wrap("rms_norm", cost_rows(1, 1))
     wrap("silu_and_mul", cost_rows(2, 1))
     wrap("rotary_embedding", lambda pos, q, k, *a: (0.0, 2.0 * (q.numel() + (k.numel() if k is not None else 0)) * 2))
-    wrap("reshape_and_cache", lambda key, value, *a, **k: (0.0, 4.0 * key.numel() * 2))
+    wrap("reshape_and_cache", lambda key, value, kc, *a, **k: (0.0, 2.0 * key.numel() * (2 + kc.element_size())))
 
 
 def max_over_ranks(elapsed: float, device, world: int) -> float:
@@ -297,13 +304,64 @@ def cpu_baseline(args, cfg):
     }
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (the
+    parent never touches the GPU), relay rank 0's JSON line, return the worst exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    return max(abs(rc) for rc in rcs)
+
+
+def timed_jobs(model, tokens, args, world, barrier, timer=None):
+    """W warm-up jobs (at least one: it builds the decode graph), then EXACTLY K timed jobs bracketed by
+    barrier + synchronize; returns (max-over-ranks seconds, ttft samples)."""
+    for _ in range(max(args.warmup, 1)):
+        run_job(model, tokens, args)
+    barrier()
+    if timer is not None:
+        timer.enabled = True
+    ttft_events, start_ev = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s = torch.cuda.Event(enable_timing=True)
+        s.record()
+        tt = []
+        run_job(model, tokens, args, ttft=tt)
+        start_ev.append(s)
+        ttft_events.append(tt)
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, model.device, world)
+    ttfts = []
+    for s, tt in zip(start_ev, ttft_events):
+        for n, ev in tt:
+            ttfts += [s.elapsed_time(ev)] * n
+    return elapsed, ttfts
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))      # (before any GPU call in this process)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}), "
+                         f"or run bench.py --gpus N without a launcher")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # rehearsal on a 1-GPU box: BENCH_DIST_BACKEND=gloo BENCH_SHARE_GPU0=1 runs N ranks on cuda:0
@@ -321,10 +379,16 @@ def main():
         group = torch.distributed.group.WORLD
 
     from vllm_metax_amd import harness
-    tp = world if args.parallelism == "tp" else 1
-    cfg = harness.ModelConfig.llama3_8b(args.quant, tp=tp) if args.model == "llama-3-8b" \
-        else harness.ModelConfig.tiny(args.quant)
-    cfg.tp = tp
+    parallelism = args.parallelism or ("tp" if world > 1 else "dp")
+    tp = world if parallelism == "tp" else 1
+
+    def make_cfg(tp_degree):
+        cfg = harness.ModelConfig.llama3_8b(args.quant) if args.model == "llama-3-8b" \
+            else harness.ModelConfig.tiny(args.quant)
+        cfg.tp, cfg.tp_rank = tp_degree, (rank if tp_degree > 1 else 0)
+        cfg.kv_cache_dtype = args.kv_cache_dtype
+        return cfg
+    cfg = make_cfg(tp)
     max_len = args.input_len + args.output_len
     model = harness.HotPathModel(cfg, args.batch, max_len, device=f"cuda:{local_rank}", seed=0,
                                  tp_group=group if tp > 1 else None)
@@ -345,30 +409,8 @@ def main():
     # afterwards by a few eager decode steps on the same stream.
     timer = EventTimer()
     instrument(model, timer)
-    for _ in range(max(args.warmup, 1)):   # at least one: builds the decode graph
-        run_job(model, tokens, args)
-    barrier()
-    timer.enabled = True
-
     # ---- timed region: exactly K jobs -------------------------------------------------
-    ttft_events = []
-    start_ev = []
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        s = torch.cuda.Event(enable_timing=True)
-        s.record()
-        tt = []
-        run_job(model, tokens, args, ttft=tt)
-        start_ev.append(s)
-        ttft_events.append(tt)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = max_over_ranks(elapsed, model.device, world)
-
-    ttfts = []
-    for s, tt in zip(start_ev, ttft_events):
-        for n, ev in tt:
-            ttfts += [s.elapsed_time(ev)] * n
+    elapsed, ttfts = timed_jobs(model, tokens, args, world, barrier, timer)
     ttft_p50 = statistics.median(ttfts) if ttfts else None
 
     # ---- decode kernels: 8 eager decode steps at the mean decode context, bracketed ----------
@@ -387,11 +429,17 @@ def main():
             ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
             peak = MFMA_8BIT_PEAK_TFLOPS if name.startswith(("fp8_gemm", "int8_gemm")) \
                 else MFMA_BF16_PEAK_TFLOPS
-            return {"kernel": name, "bound": "mfma", "achieved": round(ach, 2),
-                    "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
-                    "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
-                    "total_ms": round(d["ms"], 2)}
+            r = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2),
+                 "peak": peak, "unit": "TFLOP/s",
+                 "frac": round(ach / peak, 4), "traffic": None,
+                 "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
+                 "total_ms": round(d["ms"], 2)}
+            if name.endswith("gemm_large_m"):
+                # north_star words its GEMM target against the fp8 MFMA peak (5 PFLOP/s dense); the
+                # w4a16 GEMM multiplies bf16 operands, so `frac` is against the bf16 peak and this
+                # field restates the same rate against the fp8 peak (SURVEY §8d asks for both)
+                r["frac_fp8_peak"] = round(ach / MFMA_8BIT_PEAK_TFLOPS, 4)
+            return r
         ach = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
@@ -402,7 +450,7 @@ def main():
     # HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of
     # the same kernels at the same shapes; a counter pass cannot run inside the timed region)
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath) and args.model == "llama-3-8b" and tp == 1:
+    if os.path.exists(tpath) and args.model == "llama-3-8b" and tp == 1 and args.kv_cache_dtype == "auto":
         with open(tpath) as f:
             traffic = json.load(f)
         for r in roofs:
@@ -413,7 +461,28 @@ def main():
         for r in roofs:
             print(json.dumps(r), file=sys.stderr)
 
+    # ---- tp runs: the collective-free alternative (one replica per GPU) measured in the same run ----
+    dp_extra = None
+    if tp > 1 and not args.no_dp_extra:
+        graph_ok, graph_err = model._graph not in (None, False), model.graph_error
+        del model
+        torch.cuda.empty_cache()
+        rep_model = harness.HotPathModel(make_cfg(1), args.batch, max_len, device=f"cuda:{local_rank}", seed=0)
+        rep_model.setup_decode(args.batch, args.input_len, max_len)
+        rep_model.cfg_ctx_for_cost = 0
+        rep_model.mean_decode_len_for_cost = args.input_len + (args.output_len - 1) / 2.0 + 1
+        dp_elapsed, _ = timed_jobs(rep_model, tokens, args, world, barrier)
+        dp_extra = {"value": round(whole_job_tokens(args.steps, args.batch, args.output_len, world, 1) / dp_elapsed, 2),
+                    "unit": "output tokens/s", "scaling": "weak", "ms_per_step": round(dp_elapsed / args.steps * 1e3, 3),
+                    "global_batch": args.batch * world,
+                    "note": "one model replica per GPU, each serving its own batch: no data-path collective"}
+    else:
+        graph_ok, graph_err = model._graph not in (None, False), model.graph_error
+
     if rank != 0:
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
         return
     replicas = world if tp == 1 else 1       # dp: every rank served its own batch
     out_tokens = whole_job_tokens(args.steps, args.batch, args.output_len, world, tp)
@@ -435,18 +504,29 @@ def main():
                                f"decode steps (1 step = 1 whole job)",
                    "batch": args.batch, "global_batch": args.batch * replicas,
                    "input_len": args.input_len, "output_len": args.output_len,
-                   "parallelism": f"tp{world}" if tp > 1 else f"dp{world}", "kv_block_size": 16},
+                   "parallelism": f"tp{world}" if tp > 1 else f"dp{world}", "kv_block_size": 16,
+                   "kv_cache_dtype": args.kv_cache_dtype,
+                   "decode_graph": bool(graph_ok) and not args.no_graph,
+                   "collectives": ("RCCL all-reduce x2 per layer + all-gather of the logits, captured in the "
+                                   "decode graph" if tp > 1 else "none on the data path")},
         "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
         "roofline": roofs[0] if roofs else None,
         "roofline_other": roofs[1:],
     }
+    if graph_err:
+        result["config"]["decode_graph_error"] = graph_err
+    if dp_extra is not None:
+        result["dp_replicas"] = dp_extra
     if world == 1 and not args.skip_cpu:
         try:
             result["cpu_baseline"] = cpu_baseline(args, cfg)
         except Exception as e:  # the baseline must never take the GPU number down with it
             result["cpu_baseline"] = {"value": None, "unit": "output tokens/s", "cores": 0,
                                       "kind": "port", "sample": f"failed: {e!r}"}
-    print(json.dumps(result))
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

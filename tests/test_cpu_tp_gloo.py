@@ -169,3 +169,94 @@ def test_dp_replica_aggregation_world2():
     for p in ps:
         p.join(60)
     assert got == {0: 2.0, 1: 2.0}
+
+
+# ---------------------------------------------------------------------------------------------
+# The harness itself under tensor parallelism (the test above re-implements the layer;
+# vllm_metax_amd/harness.py's own TP branch was never executed).  Here harness.HotPathModel runs on
+# the CPU with its op surface replaced by the oracle (tests/oracle_ops_shim.py): world_size 2 over
+# gloo, every rank builds ITS shard of the same model (QLinear cuts it out of the full layer), runs
+# a prefill chunk and decode steps with the real all-reduce / all-gather placement, and the greedy
+# tokens must equal those of the unsharded model.
+def _install_shim():
+    from tests import oracle_ops_shim as shim
+    from vllm_metax_amd import harness
+    from vllm_metax_amd.attention import backend
+    harness.ops = shim
+    backend.ops = shim
+    backend.v1_max_seq_len.cache_clear()
+    return harness
+
+
+def _tiny_cfg(harness, tp, rank, quant="awq"):
+    cfg = harness.ModelConfig.tiny(quant)
+    cfg.group_size = 64
+    cfg.tp, cfg.tp_rank = tp, rank
+    return cfg
+
+
+def _harness_tokens(harness, cfg, group, steps=3):
+    torch.manual_seed(0)
+    model = harness.HotPathModel(cfg, 3, 48, device="cpu", dtype=torch.bfloat16, seed=0, tp_group=group)
+    model.setup_decode(3, 20, 48)
+    tok = torch.randint(0, cfg.vocab, (3, 20), generator=torch.Generator().manual_seed(5))
+    first = model.prefill(tok, [0, 1, 2], 0)
+    model.d_tokens.copy_(first)
+    model.set_decode_lengths(torch.full((3,), 20))
+    out = [first.clone()]
+    for _ in range(steps):
+        model.decode_step(use_graph=False)
+        out.append(model.d_tokens.clone())
+    return torch.stack(out)
+
+
+def _harness_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    harness = _install_shim()
+    toks = _harness_tokens(harness, _tiny_cfg(harness, world, rank), dist.group.WORLD)
+    if rank == 0:
+        q.put(toks.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_harness_tp2_tokens_equal_tp1():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_harness_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    toks_tp = q.get(timeout=500)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    harness = _install_shim()
+    toks_1 = _harness_tokens(harness, _tiny_cfg(harness, 1, 0), None).numpy()
+    assert toks_tp.shape == toks_1.shape == (4, 3)
+    assert (toks_tp == toks_1).all(), f"TP=2 tokens {toks_tp.tolist()} != TP=1 tokens {toks_1.tolist()}"
+
+
+def test_qlinear_shards_are_slices_of_the_full_layer():
+    """Column / row shards cut by QLinear reproduce x @ W_full restricted to the shard (oracle GEMM)."""
+    harness = _install_shim()
+    cfg = harness.ModelConfig.tiny("awq")
+    cfg.group_size = 64
+    k, n = 256, 384
+    x = (torch.randn(5, k, generator=torch.Generator().manual_seed(1)) * 0.5).to(torch.bfloat16)
+
+    def mk(**kw):
+        return harness.QLinear(k, n, cfg, torch.bfloat16, "cpu", torch.Generator().manual_seed(7), **kw)
+    full = mk()(x)
+    cols = [(64, 64), (256, 32)]
+    part = mk(cols=cols)(x)
+    assert torch.equal(part, torch.cat([full[:, a:a + l] for a, l in cols], dim=1))
+    # row shards: partial sums add up to the full product (fp32 accumulate, then one rounding)
+    lo = mk(rows=(0, 128))(x[:, :128].contiguous())
+    hi = mk(rows=(128, 128))(x[:, 128:].contiguous())
+    err = (lo.float() + hi.float() - full.float()).abs().max().item()
+    assert err <= 2.0 ** -6 * full.float().abs().max().item()

@@ -40,6 +40,8 @@ class ModelConfig:
     quant: str = "awq"          # "awq" | "gptq" | "fp8" | "int8" | "none"
     group_size: int = 128
     tp: int = 1                 # tensor-parallel degree (heads / ffn sharded, all-reduce after o/down)
+    tp_rank: int = 0            # this process's shard
+    kv_cache_dtype: str = "auto"   # "auto" | "fp8" (e4m3 KV cache)
 
     @staticmethod
     def llama3_8b(quant="awq", tp=1):
@@ -62,39 +64,64 @@ class ModelConfig:
 
 
 class QLinear:
-    """One (column- or row-parallel shard of a) linear layer with synthetic weights."""
+    """One (column- or row-parallel shard of a) linear layer with synthetic weights.
 
-    def __init__(self, k: int, n: int, cfg: ModelConfig, dtype, device, gen):
-        self.k, self.n, self.quant, self.group = k, n, cfg.quant, cfg.group_size
+    The FULL [k, n] layer is always generated (same generator consumption on every rank and for
+    every tp), then the shard is cut out: `cols` = list of (start, length) column segments kept
+    (column-parallel: qkv, gate_up), `rows` = (start, length) of the K range kept (row-parallel: o,
+    down) — so a TP=N model is a true sharding of the TP=1 model and produces the same tokens.
+    Segment bounds are multiples of 8 columns (packed words) / of the group size (rows)."""
+
+    def __init__(self, k: int, n: int, cfg: ModelConfig, dtype, device, gen, cols=None, rows=None):
+        self.quant, self.group = cfg.quant, cfg.group_size
         self.dtype = dtype
+        g = self.group
+
+        def ccut(t, unit=1):          # keep the column segments of the last dim (in units of `unit` cols)
+            if cols is None:
+                return t
+            return torch.cat([t[..., a // unit:(a + l) // unit] for a, l in cols], dim=-1).contiguous()
+
+        def rcut(t, unit=1):          # keep the row range of dim 0 (in units of `unit` rows)
+            if rows is None:
+                return t
+            return t[rows[0] // unit:(rows[0] + rows[1]) // unit].contiguous()
+
         if cfg.quant == "awq":
             qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (k, n // 8), dtype=torch.int32, device=device,
                                generator=gen)
-            self.qweight = ops.awq_to_gptq_4bit(qw)                       # exllama layout
-            self.qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (k // self.group, n // 8),
-                                        dtype=torch.int32, device=device, generator=gen)
-            self.scales = (torch.rand(k // self.group, n, device=device, generator=gen) * 4e-3
-                           + 1e-3).to(dtype)
+            qz = torch.randint(-2 ** 31, 2 ** 31 - 1, (k // g, n // 8), dtype=torch.int32, device=device,
+                               generator=gen)
+            sc = (torch.rand(k // g, n, device=device, generator=gen) * 4e-3 + 1e-3).to(dtype)
+            self.qweight = ops.awq_to_gptq_4bit(rcut(ccut(qw, 8)))        # exllama layout
+            self.qzeros = rcut(ccut(qz, 8), g)
+            self.scales = rcut(ccut(sc), g)
         elif cfg.quant == "gptq":
-            self.qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (k // 8, n), dtype=torch.int32,
-                                         device=device, generator=gen)
+            qw = torch.randint(-2 ** 31, 2 ** 31 - 1, (k // 8, n), dtype=torch.int32, device=device,
+                               generator=gen)
+            sc = (torch.rand(k // g, n, device=device, generator=gen) * 4e-3 + 1e-3).to(dtype)
+            self.qweight = rcut(ccut(qw), 8)
             ops.gptq_shuffle(self.qweight, torch.empty(0, dtype=torch.int32), 4)
-            self.qzeros = torch.full((k // self.group, n // 8), 0x77777777, dtype=torch.int32,
-                                     device=device)                       # symmetric (stored zero 7)
-            self.scales = (torch.rand(k // self.group, n, device=device, generator=gen) * 4e-3
-                           + 1e-3).to(dtype)
+            self.scales = rcut(ccut(sc), g)
+            self.qzeros = torch.full((self.scales.shape[0], self.scales.shape[1] // 8), 0x77777777,
+                                     dtype=torch.int32, device=device)    # symmetric (stored zero 7)
             self.g_idx = torch.empty(0, dtype=torch.int32, device=device)
         elif cfg.quant == "fp8":
-            w = torch.randn(n, k, device=device, generator=gen).clamp_(-448, 448)
-            self.weight = w.to(torch.float8_e4m3fn).t()                  # [K, N] column-major
-            self.w_scale = (torch.rand(1, n, device=device, generator=gen) * 4e-3 + 1e-3)
+            w = torch.randn(n, k, device=device, generator=gen).clamp_(-448, 448)      # [N, K]
+            ws = (torch.rand(1, n, device=device, generator=gen) * 4e-3 + 1e-3)
+            self.weight = rcut(ccut(w.t())).t().contiguous().to(torch.float8_e4m3fn).t()   # [K, N] column-major
+            self.w_scale = ccut(ws)
         elif cfg.quant == "int8":
             # W8A8 (compressed-tensors style): per-channel int8 weights, dynamic per-token activations
             w = torch.randint(-127, 128, (n, k), dtype=torch.int32, device=device, generator=gen)
-            self.weight = w.to(torch.int8).t()                            # [K, N] column-major
-            self.w_scale = (torch.rand(1, n, device=device, generator=gen) * 4e-5 + 1e-5)
+            ws = (torch.rand(1, n, device=device, generator=gen) * 4e-5 + 1e-5)
+            self.weight = rcut(ccut(w.t())).t().contiguous().to(torch.int8).t()          # [K, N] column-major
+            self.w_scale = ccut(ws)
         else:
-            self.weight = (torch.randn(k, n, device=device, generator=gen) * 0.02).to(dtype)
+            w = (torch.randn(k, n, device=device, generator=gen) * 0.02).to(dtype)
+            self.weight = rcut(ccut(w))
+        self.k = rows[1] if rows is not None else k
+        self.n = sum(l for _, l in cols) if cols is not None else n
         self._ws = {}
 
     _shared_ws = {}   # device -> fp32 split-K scratch shared by every layer (stream-ordered use)
@@ -168,16 +195,33 @@ class QLinear:
 
 
 class Layer:
+    """One decoder layer, sharded Megatron-style for tp > 1: qkv / gate_up column-
+    parallel (rank r owns q heads [r H/tp, ..), kv heads [r KVH/tp, ..), ffn columns [r F/tp, ..)),
+    o_proj / down_proj row-parallel over the matching K range (their outputs are all-reduced)."""
+
     def __init__(self, cfg: ModelConfig, dtype, device, gen):
         h, d = cfg.hidden, cfg.head_dim
-        self.q_heads = cfg.heads // cfg.tp
-        self.kv_heads = max(cfg.kv_heads // cfg.tp, 1)
+        tp, r = cfg.tp, cfg.tp_rank
+        if cfg.heads % tp or cfg.kv_heads % tp or cfg.ffn % tp or (cfg.ffn // tp) % cfg.group_size:
+            raise ValueError(f"tp={tp} must divide heads {cfg.heads}, kv_heads {cfg.kv_heads} and ffn {cfg.ffn} "
+                             f"(ffn/tp a multiple of the group size)")
+        self.q_heads = cfg.heads // tp
+        self.kv_heads = cfg.kv_heads // tp
         self.q_size, self.kv_size = self.q_heads * d, self.kv_heads * d
-        ffn = cfg.ffn // cfg.tp
-        self.qkv = QLinear(h, self.q_size + 2 * self.kv_size, cfg, dtype, device, gen)
-        self.o = QLinear(self.q_size, h, cfg, dtype, device, gen)
-        self.gate_up = QLinear(h, 2 * ffn, cfg, dtype, device, gen)
-        self.down = QLinear(ffn, h, cfg, dtype, device, gen)
+        ffn = cfg.ffn // tp
+        Q, KV = cfg.heads * d, cfg.kv_heads * d
+        if tp == 1:
+            qkv_cols = gu_cols = o_rows = down_rows = None
+        else:
+            qkv_cols = [(r * self.q_size, self.q_size), (Q + r * self.kv_size, self.kv_size),
+                        (Q + KV + r * self.kv_size, self.kv_size)]
+            gu_cols = [(r * ffn, ffn), (cfg.ffn + r * ffn, ffn)]
+            o_rows = (r * self.q_size, self.q_size)
+            down_rows = (r * ffn, ffn)
+        self.qkv = QLinear(h, Q + 2 * KV, cfg, dtype, device, gen, cols=qkv_cols)
+        self.o = QLinear(Q, h, cfg, dtype, device, gen, rows=o_rows)
+        self.gate_up = QLinear(h, 2 * cfg.ffn, cfg, dtype, device, gen, cols=gu_cols)
+        self.down = QLinear(cfg.ffn, h, cfg, dtype, device, gen, rows=down_rows)
         self.ln1 = (torch.rand(h, device=device, generator=gen) * 0.2 + 0.9).to(dtype)
         self.ln2 = (torch.rand(h, device=device, generator=gen) * 0.2 + 0.9).to(dtype)
         self.ffn = ffn
@@ -196,9 +240,10 @@ class HotPathModel:
         self.layers: List[Layer] = [Layer(cfg, dtype, self.device, gen) for _ in range(cfg.layers)]
         self.embed = (torch.randn(cfg.vocab, cfg.hidden, device=self.device, generator=gen)
                       * 0.02).to(dtype)
-        vshard = cfg.vocab // cfg.tp
-        self.lm_head = (torch.randn(cfg.hidden, vshard, device=self.device, generator=gen)
-                        * 0.02).to(dtype)
+        vshard = cfg.vocab // cfg.tp            # vocab-parallel lm_head: a column slice of the full matrix
+        lm_full = (torch.randn(cfg.hidden, cfg.vocab, device=self.device, generator=gen) * 0.02).to(dtype)
+        self.lm_head = lm_full[:, cfg.tp_rank * vshard:(cfg.tp_rank + 1) * vshard].contiguous()
+        del lm_full
         self.final_norm = torch.ones(cfg.hidden, dtype=dtype, device=self.device)
         d = cfg.head_dim
         inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, device=self.device).float() / d))
@@ -210,20 +255,32 @@ class HotPathModel:
         self.blocks_per_seq = (max_len + self.BLOCK - 1) // self.BLOCK
         nb = max_seqs * self.blocks_per_seq
         kvh = self.layers[0].kv_heads
-        x = 16 // torch.tensor([], dtype=dtype).element_size()
-        self.k_cache = [torch.zeros(nb, kvh, d // x, self.BLOCK, x, dtype=dtype, device=self.device)
+        self.kv_dtype = cfg.kv_cache_dtype
+        cache_dt = dtype if self.kv_dtype == "auto" else torch.uint8      # e4m3 bytes, x = 16
+        x = 16 // torch.tensor([], dtype=cache_dt).element_size()
+        self.k_cache = [torch.zeros(nb, kvh, d // x, self.BLOCK, x, dtype=cache_dt, device=self.device)
                         for _ in range(cfg.layers)]
-        self.v_cache = [torch.zeros(nb, kvh, d, self.BLOCK, dtype=dtype, device=self.device)
+        self.v_cache = [torch.zeros(nb, kvh, d, self.BLOCK, dtype=cache_dt, device=self.device)
                         for _ in range(cfg.layers)]
+        # one float32 scale per tensor, as the schema's k_scale / v_scale (1.0: the reference tests' value)
+        self.k_scale = torch.ones(1, dtype=torch.float32, device=self.device) if self.kv_dtype != "auto" else None
+        self.v_scale = torch.ones(1, dtype=torch.float32, device=self.device) if self.kv_dtype != "auto" else None
         # block tables: a fixed random permutation of the pool (as the reference's tests do)
         perm = torch.randperm(nb, device=self.device, generator=gen).to(torch.int32)
         self.block_tables = perm.reshape(max_seqs, self.blocks_per_seq).contiguous()
         self.scale = 1.0 / math.sqrt(d)
         self._graph = None
+        self.graph_error = None
+        self.collectives_always = False
 
     # ---------------------------------------------------------------- helpers
+    def _collectives(self) -> bool:
+        # `collectives_always`: rehearsal switch — issue the collectives on a 1-rank group too, so that
+        # RCCL calls inside a captured decode graph can be exercised on a single GPU
+        return self.tp_group is not None and (self.cfg.tp > 1 or self.collectives_always)
+
     def _all_reduce(self, x: torch.Tensor) -> torch.Tensor:
-        if self.tp_group is not None and self.cfg.tp > 1:
+        if self._collectives():
             torch.distributed.all_reduce(x, group=self.tp_group)
         return x
 
@@ -246,8 +303,9 @@ class HotPathModel:
         else:
             ops.fused_add_rms_norm_slabs(x, residual, L.ln1, pending[0], pending[1], cfg.eps)
             h = x
-        if defer and x.dtype != torch.float32:
-            # decode: slab sum + rotary + cache write in one launch
+        if defer and x.dtype != torch.float32 and self.kv_dtype == "auto":
+            # decode: slab sum + rotary + cache write in one launch (column-parallel GEMM: no
+            # collective between it and the rotary, so the fusion also holds under tp)
             qkv, slabs, sk = L.qkv.deferred(h)
             ops.qkv_rope_cache(qkv, slabs, sk, positions, self.cos_sin, self.k_cache[i],
                                self.v_cache[i], slots, L.q_heads, L.kv_heads, cfg.head_dim)
@@ -259,7 +317,8 @@ class HotPathModel:
             v = qkv[:, L.q_size + L.kv_size:]
             ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin, True)
             ops.reshape_and_cache(k.view(-1, L.kv_heads, cfg.head_dim), v.view(-1, L.kv_heads, cfg.head_dim),
-                                  self.k_cache[i], self.v_cache[i], slots, "auto")
+                                  self.k_cache[i], self.v_cache[i], slots, self.kv_dtype, self.k_scale,
+                                  self.v_scale)
         attn = attn_fn(i, q.view(-1, L.q_heads, cfg.head_dim))
         if fuse:
             o, slabs, sk = L.o.deferred(attn.view(-1, L.q_size))
@@ -281,10 +340,13 @@ class HotPathModel:
     def _logits_argmax(self, x: torch.Tensor, residual: torch.Tensor, pending=(None, 0)) -> torch.Tensor:
         ops.fused_add_rms_norm_slabs(x, residual, self.final_norm, pending[0], pending[1], self.cfg.eps)
         logits = torch.matmul(x, self.lm_head)
-        if self.tp_group is not None and self.cfg.tp > 1:
-            parts = [torch.empty_like(logits) for _ in range(self.cfg.tp)]
-            torch.distributed.all_gather(parts, logits, group=self.tp_group)
-            logits = torch.cat(parts, dim=-1)
+        if self._collectives():
+            gathered = torch.empty(self.cfg.tp * logits.shape[0], logits.shape[1], dtype=logits.dtype,
+                                   device=logits.device)
+            torch.distributed.all_gather_into_tensor(gathered, logits.contiguous(), group=self.tp_group)
+            # [tp * M, V/tp] -> [M, V]: rank r owns vocabulary slice r
+            logits = gathered.view(self.cfg.tp, logits.shape[0], logits.shape[1]).permute(1, 0, 2) \
+                             .reshape(logits.shape[0], -1)
         return logits.argmax(dim=-1)
 
     # ---------------------------------------------------------------- prefill
@@ -307,7 +369,7 @@ class HotPathModel:
             out = torch.empty_like(q3)
             ops.paged_prefill_attention(out, q3, self.k_cache[i], self.v_cache[i],
                                         self.layers[i].kv_heads, self.scale, bt, seq_lens, cu,
-                                        q_len, self.BLOCK)
+                                        q_len, self.BLOCK, self.kv_dtype, self.k_scale, self.v_scale)
             return out
 
         for i in range(self.cfg.layers):
@@ -346,7 +408,8 @@ class HotPathModel:
             out = torch.empty_like(q3)
             decode_attention(out, self.d_es, self.d_ml, self.d_tmp, q3, self.k_cache[i],
                              self.v_cache[i], self.layers[i].kv_heads, self.scale, self.d_bt,
-                             self.d_seq_lens, self.BLOCK, self.d_max_seq_len)
+                             self.d_seq_lens, self.BLOCK, self.d_max_seq_len, None, self.kv_dtype,
+                             self.k_scale, self.v_scale)
             return out
 
         pending = (None, 0)
@@ -359,24 +422,50 @@ class HotPathModel:
         self.d_seq_lens.add_(1)
 
     def decode_step(self, use_graph: bool = True):
-        if not use_graph:
+        """One decode step for all sequences.  With use_graph the step is replayed from a HIP graph
+        captured on first use — under tp > 1 the RCCL all-reduces / all-gather are captured in it too
+        (torch.distributed's NCCL backend records them on the capturing stream).  If the capture
+        fails (e.g. a backend that cannot be captured, such as gloo), the error is kept in
+        `graph_error` and the step runs eagerly from then on."""
+        if not use_graph or self._graph is False:
+            self._decode_body()
+            return
+        if self._graph is None and self._collectives() and \
+                torch.distributed.get_backend(self.tp_group) != "nccl":
+            # only RCCL ("nccl") collectives can be recorded into a HIP graph; a host-staged backend
+            # (gloo rehearsals on one GPU) would invalidate the capture
+            self.graph_error = f"backend {torch.distributed.get_backend(self.tp_group)!r} cannot be captured"
+            self._graph = False
             self._decode_body()
             return
         if self._graph is None:
-            # warm up on a side stream, then capture
+            # warm up on a side stream (also initialises the communicator), then capture
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             saved = (self.d_tokens.clone(), self.d_positions.clone(), self.d_seq_lens.clone())
+
+            def restore():
+                self.d_tokens.copy_(saved[0]); self.d_positions.copy_(saved[1]); self.d_seq_lens.copy_(saved[2])
             with torch.cuda.stream(s):
                 self._decode_body()
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            self.d_tokens.copy_(saved[0]); self.d_positions.copy_(saved[1]); self.d_seq_lens.copy_(saved[2])
+            restore()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            try:
+                # thread_local: the process group's watchdog thread may touch the runtime meanwhile
+                mode = {"capture_error_mode": "thread_local"} if self.cfg.tp > 1 else {}
+                with torch.cuda.graph(g, **mode):
+                    self._decode_body()
+                self._graph = g
+            except Exception as e:  # noqa: BLE001 - keep serving eagerly, report why
+                self.graph_error = repr(e)
+                self._graph = False
+                torch.cuda.synchronize()
+                restore()
                 self._decode_body()
-            self._graph = g
-            self.d_tokens.copy_(saved[0]); self.d_positions.copy_(saved[1]); self.d_seq_lens.copy_(saved[2])
+                return
+            restore()
         self._graph.replay()
 
     # -------------------------------------------------------------- accounting
@@ -384,6 +473,7 @@ class HotPathModel:
         """Algorithmic HBM bytes of one decode step."""
         L = self.layers[0]
         w = sum(l.weight_bytes() for l in (L.qkv, L.o, L.gate_up, L.down)) * self.cfg.layers
-        kv = num_seqs * mean_len * L.kv_heads * self.cfg.head_dim * 2 * 2 * self.cfg.layers
+        kv_elt = 2 if self.kv_dtype == "auto" else 1
+        kv = num_seqs * mean_len * L.kv_heads * self.cfg.head_dim * 2 * kv_elt * self.cfg.layers
         head = self.lm_head.numel() * 2
         return {"weights": w, "kv": kv, "lm_head": head, "total": w + kv + head}
