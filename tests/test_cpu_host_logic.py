@@ -113,15 +113,15 @@ def test_decode_kernel_choice_follows_the_upstream_rule():
     assert not use_paged_attention_v1(256, 32, 9000, *args, bf)     # beyond the upstream rule's 8192
     # the launcher's LDS budget, not a fixed 8192, bounds v1 (round-1 defect: 6721..8192 chose v1 and
     # the launcher refused it): 32/8 heads keep 4 heads' logits per workgroup
-    assert v1_max_seq_len(32, 8, 128, 16, bf) == 6720
+    assert v1_max_seq_len(32, 8, 128, 16, bf) == 6656
     assert v1_max_seq_len(32, 8, 128, 16, f32) == 4928
-    for L, want in ((6720, True), (6721, False), (7000, False), (8192, False)):
+    for L, want in ((6656, True), (6657, False), (7000, False), (8192, False)):
         assert use_paged_attention_v1(64, 32, L, *args, bf) is want, L
     assert use_paged_attention_v1(64, 32, 4928, *args, f32) and not use_paged_attention_v1(64, 32, 5100, *args, f32)
     # MHA (one head per workgroup) fits the whole upstream range
     assert use_paged_attention_v1(64, 32, 8192, 32, 128, 16, bf)
     # the pure rule
-    assert v1_v2_rule(64, 32, 7000, 8192) and not v1_v2_rule(64, 32, 7000, 6720)
+    assert v1_v2_rule(64, 32, 7000, 8192) and not v1_v2_rule(64, 32, 7000, 6656)
 
 
 def test_decode_workspace_views_and_fixed_geometry():

@@ -162,7 +162,7 @@ def v1_max_seq_len(num_heads: int, num_kv_heads: int, head_size: int, block_size
                    dtype: torch.dtype) -> int:
     """Largest context paged_attention_v1 takes for this head geometry: the launcher's own LDS budget
     (mi355x_paged_attention_v1_max_seq_len; the reference sizes its LDS the same way,
-    csrc/attention/paged_attention_v1.cu:77-87) — 6720 tokens for 32/8 heads in bf16, 4928 in fp32."""
+    csrc/attention/paged_attention_v1.cu:77-87) — 6656 tokens for 32/8 heads in bf16, 4928 in fp32."""
     return ops.paged_attention_v1_max_seq_len(1, num_heads, num_kv_heads, head_size, block_size, dtype)
 
 

@@ -40,7 +40,49 @@ namespace mi355x {
 
 constexpr int kPaThreads = 256;       // default workgroup: 4 waves
 constexpr int kPaMaxThreads = 512;    // few-workgroup launches (v1 at small batch) use 8 waves
-constexpr int kPaScratchBytes = 128;  // red[16] + s_max[4] + s_sum[4], padded
+constexpr int kPaScratchBytes = 256;  // red[GT <= 4][16] floats
+
+// 16-byte load of a K / V piece: non-temporal — the cache is streamed once per step, keeping it out of
+// L2 / MALL is worth 10 % (64 seqs x ctx 1088, v1: 54.3 -> 48.5 us, fp8 cache 34.8 -> 30.5 us;
+// profiles/r02_attn_ab2.txt).  -DPA_NO_NT builds the default-policy variant of that comparison.
+__device__ __forceinline__ uint4 ld_kv16(const void* p) {
+#ifndef PA_NO_NT
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
+// Block-wide max / sum of N values at once: ONE pair of barriers for all of them (the softmax of the
+// GT query heads of a workgroup used to pay two barriers per head and reduction).
+template <bool IS_MAX, int N>
+__device__ __forceinline__ void block_reduce_n(float (&v)[N], float* smem /* [N][16] */) {
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int g = 0; g < N; ++g) v[g] = IS_MAX ? wave_max(v[g]) : wave_sum(v[g]);
+  if (nw == 1) return;
+  __syncthreads();  // protect smem from a previous use
+  if (lane == 0) {
+#pragma unroll
+    for (int g = 0; g < N; ++g) smem[g * 16 + wid] = v[g];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < N; ++g) {
+    float r = IS_MAX ? -3.402823466e+38f : 0.f;
+    if (lane < nw) r = smem[g * 16 + lane];
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) {
+      const float o = __shfl_xor(r, m, 64);
+      r = IS_MAX ? fmaxf(r, o) : r + o;
+    }
+    v[g] = __shfl(r, 0, 64);
+  }
+}
 
 template <typename T>
 __device__ __forceinline__ float dot_chunk(const uint4& a, const uint4& b, float acc);
@@ -206,19 +248,20 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: block ids / bases on the SALU
   const int nthreads = blockDim.x;           // 256 or 512 (host: launch_pa)
   const int nwaves = nthreads >> 6;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // all LDS lives in the dynamic region so that its base stays 16-B aligned
-  float* red = reinterpret_cast<float*>(smem);                          // [16]
-  float* s_max = red + 16;                                              // [4]
-  float* s_sum = red + 20;                                              // [4]
+  float* red = reinterpret_cast<float*>(smem);                          // [GT][16]
   T* q_s = reinterpret_cast<T*>(smem + kPaScratchBytes);                // [GT][256]
   float* logits =
       reinterpret_cast<float*>(smem + kPaScratchBytes + (size_t)GT * 256 * sizeof(T));  // [GT][cap]
   T* probs = reinterpret_cast<T*>(logits + (size_t)GT * logits_cap);    // [GT][cap]
+  // physical block ids of this (sequence, partition): read once, coalesced, instead of one dependent
+  // global load in front of every K / V block
+  int* bt_s = reinterpret_cast<int*>(probs + (size_t)GT * logits_cap);  // [cap / BS]
 
   // ---- stage q (packed scalar_t) into LDS; absent heads are zero ---------------
   for (int i = tid; i < GT * CQ; i += nthreads) {
@@ -230,6 +273,8 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
     }
     *reinterpret_cast<uint4*>(q_s + g * D + c * XT) = v;
   }
+  const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+  for (int i = tid; i < end_block - start_block; i += nthreads) bt_s[i] = block_table[start_block + i];
   __syncthreads();
 
   float slope[GT];
@@ -238,28 +283,19 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
     slope[g] = (alibi_slopes != nullptr && g < nheads) ? alibi_slopes[head0 + g] : 0.f;
   }
 
-  const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
-
   // =========================== QK^T ==============================================
   const int t_in_blk = lane % BS;     // token of this lane inside a block
   const int csub = lane / BS;         // chunk phase of this lane
   float qk_max[GT];
 #pragma unroll
   for (int g = 0; g < GT; ++g) qk_max[g] = -3.402823466e+38f;
-  // fast path: i-th work item of this wave = two consecutive blocks while whole rounds of
-  // 2*nwaves blocks last, then single blocks
+  // Work split: block (start_block + i * nwaves + wave) is the i-th item of this wave (round robin:
+  // the waves' loads differ by at most one block).  K and V blocks go through TWO register buffers:
+  // the load of item i + 2 is issued as soon as item i has been consumed, so one to two 4-KiB blocks
+  // per wave (64-128 KiB per CU) are in flight all the time instead of "load two, wait, compute two".
   const int nblk_part = end_block - start_block;
-  const int full_rounds = nblk_part / (2 * nwaves);
-  auto work_item = [&](int i, int& blk, bool& two) {
-    if (i < full_rounds) {
-      blk = start_block + (i * nwaves + wave) * 2;
-      two = true;
-      return true;
-    }
-    blk = start_block + full_rounds * 2 * nwaves + (i - full_rounds) * nwaves + wave;
-    two = false;
-    return blk < end_block;
-  };
+  const int nitems = wave < nblk_part ? (nblk_part - wave + nwaves - 1) / nwaves : 0;
+  auto item_block = [&](int i) { return i * nwaves + wave; };     // index inside the partition
 
   if constexpr (HS != 0) {
     // q chunks of this lane live in registers for the whole kernel
@@ -276,73 +312,59 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
         }
       }
     }
-    // two blocks per iteration and wave -> 2*NI 16-B loads in flight per lane; the blocks that do
-    // not fill a whole round of 2*nwaves go one per wave (72 blocks on 8 waves: 4 rounds + 8
-    // singles, not 5 iterations for half of the waves and 4 for the rest)
-    for (int it = 0;; ++it) {
-      int blk;
-      bool has2;
-      if (!work_item(it, blk, has2)) break;
-      const int64_t pb0 = block_table[blk];
-      const int64_t pb1 = has2 ? block_table[blk + 1] : pb0;
-      const CT* kp0 = k_cache + pb0 * kv_block_stride + (int64_t)kv_head * kv_head_stride;
-      const CT* kp1 = k_cache + pb1 * kv_block_stride + (int64_t)kv_head * kv_head_stride;
-      uint4 k0[NI], k1[NI];
+    auto load_k = [&](int i, uint4 (&kk)[NI]) {
+      const int64_t pb = bt_s[item_block(i)];
+      const CT* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int c = csub + LPT * i;
+      for (int j = 0; j < NI; ++j) {
+        const int c = csub + LPT * j;
         const int cc = (c < C) ? c : 0;
-        k0[i] = *reinterpret_cast<const uint4*>(kp0 + (cc * BS + t_in_blk) * X);
-        k1[i] = *reinterpret_cast<const uint4*>(kp1 + (cc * BS + t_in_blk) * X);
+        kk[j] = ld_kv16(kp + (cc * BS + t_in_blk) * X);
       }
-      float a0[GT], a1[GT];
+    };
+    auto qk_block = [&](int i, const uint4 (&kk)[NI]) {
+      float acc[GT];
 #pragma unroll
-      for (int g = 0; g < GT; ++g) {
-        a0[g] = 0.f;
-        a1[g] = 0.f;
-      }
+      for (int g = 0; g < GT; ++g) acc[g] = 0.f;
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        uint4 t0[QP], t1[QP];             // the piece as scalar_t (converted once, used by GT heads)
-        Piece<T, CT>::cvt(k0[i], t0);
-        Piece<T, CT>::cvt(k1[i], t1);
+      for (int j = 0; j < NI; ++j) {
+        uint4 t[QP];                      // the piece as scalar_t (converted once, used by GT heads)
+        Piece<T, CT>::cvt(kk[j], t);
 #pragma unroll
-        for (int g = 0; g < GT; ++g) {
-          a0[g] = Piece<T, CT>::dot(t0, qreg[g][i], a0[g]);
-          a1[g] = Piece<T, CT>::dot(t1, qreg[g][i], a1[g]);
-        }
+        for (int g = 0; g < GT; ++g) acc[g] = Piece<T, CT>::dot(t, qreg[g][j], acc[g]);
       }
 #pragma unroll
       for (int g = 0; g < GT; ++g) {
 #pragma unroll
-        for (int m = BS; m < 64; m <<= 1) {
-          a0[g] += __shfl_xor(a0[g], m, 64);
-          a1[g] += __shfl_xor(a1[g], m, 64);
-        }
+        for (int m = BS; m < 64; m <<= 1) acc[g] += __shfl_xor(acc[g], m, 64);
       }
       if (csub == 0) {
-        const int tok0 = blk * BS + t_in_blk;
-        const int tok1 = tok0 + BS;
+        const int loc = item_block(i) * BS + t_in_blk;        // token index inside the partition
+        const int tok = start_token + loc;
+        const bool msk = tok >= seq_len;
 #pragma unroll
         for (int g = 0; g < GT; ++g) {
-          float v0 = a0[g] * scale;
-          float v1 = a1[g] * scale;
-          v0 += (slope[g] != 0.f) ? slope[g] * (tok0 - seq_len + 1) : 0.f;
-          v1 += (slope[g] != 0.f) ? slope[g] * (tok1 - seq_len + 1) : 0.f;
-          const bool m0 = tok0 >= seq_len;
-          logits[g * logits_cap + tok0 - start_token] = m0 ? 0.f : v0;
-          qk_max[g] = m0 ? qk_max[g] : fmaxf(qk_max[g], v0);
-          if (has2) {
-            const bool m1 = tok1 >= seq_len;
-            logits[g * logits_cap + tok1 - start_token] = m1 ? 0.f : v1;
-            qk_max[g] = m1 ? qk_max[g] : fmaxf(qk_max[g], v1);
-          }
+          float v = acc[g] * scale;
+          v += (slope[g] != 0.f) ? slope[g] * (tok - seq_len + 1) : 0.f;
+          logits[g * logits_cap + loc] = msk ? 0.f : v;
+          qk_max[g] = msk ? qk_max[g] : fmaxf(qk_max[g], v);
         }
+      }
+    };
+    uint4 ka[NI], kb[NI];
+    if (nitems > 0) load_k(0, ka);
+    if (nitems > 1) load_k(1, kb);
+    for (int i = 0; i < nitems; i += 2) {
+      qk_block(i, ka);
+      if (i + 2 < nitems) load_k(i + 2, ka);
+      if (i + 1 < nitems) {
+        qk_block(i + 1, kb);
+        if (i + 3 < nitems) load_k(i + 3, kb);
       }
     }
   } else {
     for (int blk = start_block + wave; blk < end_block; blk += nwaves) {
-      const int64_t pb = block_table[blk];
+      const int64_t pb = bt_s[blk - start_block];
       const CT* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
       float a[GT];
 #pragma unroll
@@ -382,14 +404,14 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   const int tq = lane % TPP0;     // which 16-B piece (X tokens) of a V row
   const int dsub = lane / TPP0;   // V row phase
   auto load_v = [&](int blk, uint4 (&vv)[NIV]) {
-    const int64_t pb = block_table[blk];
+    const int64_t pb = bt_s[blk - start_block];
     const CT* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
     const bool last = (blk == num_seq_blocks - 1);
 #pragma unroll
     for (int i = 0; i < NIV; ++i) {
       const int d = dsub + DPI0 * i;
       if (d < D) {
-        uint4 v = *reinterpret_cast<const uint4*>(vp + (int64_t)d * BS + tq * X);
+        uint4 v = ld_kv16(vp + (int64_t)d * BS + tq * X);
         if (last) v = mask_tail<CT>(v, blk * BS + tq * X, seq_len);
         vv[i] = v;
       } else {
@@ -399,51 +421,42 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   };
   uint4 vpre0[NIV], vpre1[NIV];
   if constexpr (HS != 0) {
-    int blk;
-    bool two;
-    if (work_item(0, blk, two)) {
-      load_v(blk, vpre0);
-      if (two) load_v(blk + 1, vpre1);
-    }
+    if (nitems > 0) load_v(start_block + item_block(0), vpre0);
+    if (nitems > 1) load_v(start_block + item_block(1), vpre1);
   }
 
   // =========================== softmax ===========================================
-#pragma unroll
-  for (int g = 0; g < GT; ++g) {
-    const float m = block_reduce<true>(qk_max[g], red);
-    if (tid == 0) s_max[g] = m;
-  }
-  __syncthreads();
+  block_reduce_n<true, GT>(qk_max, red);          // every thread now holds the GT maxima
   float lsum[GT];
 #pragma unroll
   for (int g = 0; g < GT; ++g) {
     lsum[g] = 0.f;
-    const float m = s_max[g];
+    const float m = qk_max[g];
     for (int i = tid; i < num_tokens; i += nthreads) {
       const float e = __expf(logits[g * logits_cap + i] - m);
       logits[g * logits_cap + i] = e;
       lsum[g] += e;
     }
   }
-#pragma unroll
-  for (int g = 0; g < GT; ++g) {
-    const float s = block_reduce<false>(lsum[g], red);
-    if (tid == 0) s_sum[g] = s;
-  }
-  __syncthreads();
+  block_reduce_n<false, GT>(lsum, red);           // (its first barrier also orders the logits writes)
   const int padded_tokens = (end_block - start_block) * BS;
 #pragma unroll
   for (int g = 0; g < GT; ++g) {
-    const float inv = __fdividef(1.f, s_sum[g] + 1e-6f);
+    const float inv = __fdividef(1.f, lsum[g] + 1e-6f);
     for (int i = tid; i < padded_tokens; i += nthreads) {
       const float p = (i < num_tokens) ? logits[g * logits_cap + i] * inv : 0.f;
       probs[g * logits_cap + i] = from_f32<T>(p);
     }
   }
-  if (partitioned && tid < nheads) {
-    const int64_t o = ((int64_t)seq * num_heads + head0 + tid) * num_parts + part;
-    max_logits[o] = s_max[tid];
-    exp_sums[o] = s_sum[tid];
+  if (partitioned && tid == 0) {
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+      if (g < nheads) {
+        const int64_t o = ((int64_t)seq * num_heads + head0 + g) * num_parts + part;
+        max_logits[o] = qk_max[g];
+        exp_sums[o] = lsum[g];
+      }
+    }
   }
   __syncthreads();
 
@@ -475,23 +488,13 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   };
 
   if constexpr (HS != 0) {
-    // software pipeline: the loads of work item i+1 are issued before the math of item i
-    for (int it = 0;; ++it) {
-      int blk, nblk2;
-      bool has2, nhas2;
-      if (!work_item(it, blk, has2)) break;
-      const bool more = work_item(it + 1, nblk2, nhas2);
-      uint4 n0[NIV], n1[NIV];
-      if (more) {
-        load_v(nblk2, n0);
-        if (nhas2) load_v(nblk2 + 1, n1);
-      }
-      pv_block(blk, vpre0);
-      if (has2) pv_block(blk + 1, vpre1);
-#pragma unroll
-      for (int i = 0; i < NIV; ++i) {
-        vpre0[i] = n0[i];
-        vpre1[i] = n1[i];
+    // two buffers: the load of item i + 2 goes out as soon as item i has been multiplied
+    for (int i = 0; i < nitems; i += 2) {
+      pv_block(start_block + item_block(i), vpre0);
+      if (i + 2 < nitems) load_v(start_block + item_block(i + 2), vpre0);
+      if (i + 1 < nitems) {
+        pv_block(start_block + item_block(i + 1), vpre1);
+        if (i + 3 < nitems) load_v(start_block + item_block(i + 3), vpre1);
       }
     }
   } else {
@@ -630,7 +633,9 @@ static PaPlan pa_plan(int num_seqs, int num_heads, int num_kv_heads, int head_si
   const int min_cap = (p.threads / 64) * head_size;
   if (p.logits_cap < min_cap) p.logits_cap = min_cap;
   p.logits_cap = (p.logits_cap + 63) & ~63;
-  p.smem = kPaScratchBytes + (size_t)p.gt * 256 * elt_size + (size_t)p.gt * p.logits_cap * (4 + elt_size);
+  // + the block ids of the (sequence, partition): logits_cap / block_size ints
+  p.smem = kPaScratchBytes + (size_t)p.gt * 256 * elt_size + (size_t)p.gt * p.logits_cap * (4 + elt_size) +
+           (size_t)(p.logits_cap / block_size) * 4;
   return p;
 }
 
@@ -752,7 +757,8 @@ int mi355x_paged_attention_v1_max_seq_len(int num_seqs, int num_heads, int num_k
   const PaPlan p = pa_plan(num_seqs > 0 ? num_seqs : 1, num_heads, num_kv_heads, head_size, block_size,
                            esz, block_size, 0);
   const size_t fixed = kPaScratchBytes + (size_t)p.gt * 256 * esz;
-  int64_t cap = (int64_t)((kPaLdsLimit - fixed) / ((size_t)p.gt * (4 + esz)));
+  // per token: gt * (fp32 logit + scalar_t probability) + 4 / block_size bytes of block id
+  int64_t cap = (int64_t)((kPaLdsLimit - fixed) * block_size / ((size_t)p.gt * (4 + esz) * block_size + 4));
   cap &= ~(int64_t)63;                       // the launcher rounds the logits capacity up to 64
   return (int)cap;                           // = the largest max_seq_len whose padded length fits
 }
