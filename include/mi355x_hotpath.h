@@ -335,6 +335,27 @@ int mi355x_awq_gemm_packed_a(void* out, const void* a_packed, const uint32_t* qw
 int mi355x_gptq_shuffle(uint32_t* q_weight, const int* q_perm, uint32_t* scratch, int k,
                         int n, int bit, mi355x_stream stream);
 
+/* Weight-load-time preprocessing for the prefill GEMM (MI355X-side, no reference op): the prefill path
+ * (m >= 1024) multiplies operand images (1-KiB pieces [16-row tile][K/32][64 slots][8 x T], see
+ * DESIGN.md §2) and otherwise re-derives the weights' image from the int4 words on EVERY call.
+ * mi355x_w4a16_prepack writes that image once: image[n * k] elements of T = T(fma(q, s, -z s)), the
+ * reference's dequantised value (hgemm_gptq.h:487-570) bit for bit, so a GEMM on the image is
+ * bit-identical to mi355x_awq_gemm / _gptq_gemm at the same m.  qweight is the exllama layout
+ * (awq_to_gptq_4bit / gptq_shuffle output); gptq_zeros != 0: zero = qzeros + 1.
+ * Costs n * k * sizeof(T) bytes of HBM per layer (Llama-3-8B: 436 MB per decoder layer). */
+int mi355x_w4a16_prepack(void* image, const uint32_t* qweight, const void* scales,
+                         const uint32_t* qzeros, int n, int k, int group_size, int gptq_zeros, int dtype,
+                         mi355x_stream stream);
+/* out[m, n] = a[m, k] . W  with W given as a prepacked image; mode bits:
+ *   SILU      out = silu_and_mul(a . W) [m, n/2] (gate_up projection, as mi355x_awq_gemm_silu_mul)
+ *   OUT_IMAGE with SILU: write it as the operand image of the next GEMM (as .._silu_mul_packed)
+ *   A_IMAGE   `a` already is an operand image (as mi355x_awq_gemm_packed_a)
+ * a_workspace: roundup(m,16) * k * sizeof(T) bytes for the activation image (unused with A_IMAGE). */
+enum { MI355X_PREPACKED_SILU = 1, MI355X_PREPACKED_OUT_IMAGE = 2, MI355X_PREPACKED_A_IMAGE = 4 };
+int mi355x_w4a16_gemm_prepacked(void* out, const void* a, const void* image, void* a_workspace,
+                                int64_t a_workspace_bytes, int m, int n, int k, int64_t lda, int mode,
+                                int dtype, mi355x_stream stream);
+
 /* gptq_gemm: C = A[:, perm] . ((Q - (Z + 1)) * S), 4-bit, shuffled layout.
  * g_idx == NULL => no act-order; else g_idx is the argsort permutation and
  * perm_space (>= m*k elements of 2 bytes) receives the permuted activations.

@@ -202,8 +202,25 @@ def test_torch_ops_bindings_match_ctypes_path():
                                     0, 0, 0, 64, 0)
     assert_bit_exact(o1, o2, "paged_attention_v1 binding")
     with pytest.raises(RuntimeError, match="kv cache"):
+        torch.ops._C.paged_attention_v1(o2, q, kc, vc, 1, 0.088, bt, sl, 16, 530, None, "fp8_e5m2", one, one,
+                                        0, 0, 0, 64, 0)
+    with pytest.raises(RuntimeError, match="1-byte cache"):           # "fp8" needs an e4m3 byte cache
         torch.ops._C.paged_attention_v1(o2, q, kc, vc, 1, 0.088, bt, sl, 16, 530, None, "fp8", one, one,
                                         0, 0, 0, 64, 0)
+    # fp8 (e4m3) KV cache through the torch.ops surface == the ctypes path, bit for bit
+    kv_h, hd = kc.shape[1], q.shape[-1]
+    kc8 = torch.randint(0, 120, (kc.shape[0], kv_h, hd // 16, 16, 16), dtype=torch.uint8, device=d)
+    vc8 = torch.randint(0, 120, (kc.shape[0], kv_h, hd, 16), dtype=torch.uint8, device=d)
+    half = torch.full((1,), 0.5, device=d)
+    ops().paged_attention_v1(o1, q, kc8, vc8, kv_h, 0.088, bt, sl, 16, 530, None, "fp8", half, one)
+    torch.ops._C.paged_attention_v1(o2, q, kc8, vc8, kv_h, 0.088, bt, sl, 16, 530, None, "fp8", half, one,
+                                    0, 0, 0, 64, 0)
+    assert_bit_exact(o1, o2, "paged_attention_v1 fp8 binding")
+    src = torch.randn(64, 16, device=d).to(torch.bfloat16)
+    b1, b2 = torch.empty(64, 16, dtype=torch.uint8, device=d), torch.empty(64, 16, dtype=torch.uint8, device=d)
+    ops().convert_fp8(b1, src, 0.5, "fp8")
+    torch.ops._C_cache_ops.convert_fp8(b2, src, 0.5, "fp8")
+    assert_bit_exact(b1, b2, "convert_fp8 binding")
     zz = G.load("w4a16")
     qw = G.i32(zz["awq_qweight"]).to(d)
     assert torch.equal(torch.ops._C.awq_to_gptq_4bit(qw), ops().awq_to_gptq_4bit(qw))

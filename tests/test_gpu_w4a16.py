@@ -295,3 +295,44 @@ def test_gate_up_silu_into_packed_operand_then_down_is_bit_identical(dtype, m, k
     out = ops().awq_gemm_packed_a(packed, q2d2, qz2, sc2)
     assert_bit_exact(out, ref, "down_proj from the packed image")
     assert ops().awq_gemm_silu_mul_packed(x[:512], q2d, qz, sc) is None     # M < 1024
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("quant", ["awq", "gptq"])
+def test_prepacked_weight_image_is_bit_identical(dtype, quant):
+    """mi355x_w4a16_prepack + mi355x_w4a16_gemm_prepacked (the weights' operand image computed once at
+    load time) against the per-call path: plain, SILU epilogue, and SILU -> operand image -> down_proj."""
+    d = dev()
+    m, k, ffn, n2 = 1100, 256, 512, 192
+    x = (torch.randn(m, k, generator=torch.Generator().manual_seed(3)) * 0.5).to(dtype).to(d)
+    if quant == "awq":
+        qw, qz, sc, _, _ = make_awq(k, 2 * ffn, 128, dtype, seed=1)
+        qg = ops().awq_to_gptq_4bit(qw.to(d))
+        qw2, qz2, sc2, _, _ = make_awq(ffn, n2, 128, dtype, seed=2)
+        qg2 = ops().awq_to_gptq_4bit(qw2.to(d))
+        gemm = lambda a, w, z, s: ops().awq_gemm(a, w, z, s, 8, torch.empty(0), dtype == torch.bfloat16)   # noqa: E731
+    else:
+        qw, qz, sc = make_gptq(k, 2 * ffn, 128, dtype, seed=1)
+        qg = qw.to(d)
+        ops().gptq_shuffle(qg, torch.empty(0, dtype=torch.int32), 4)
+        qw2, qz2, sc2 = make_gptq(ffn, n2, 128, dtype, seed=2)
+        qg2 = qw2.to(d)
+        ops().gptq_shuffle(qg2, torch.empty(0, dtype=torch.int32), 4)
+        e = torch.empty(0, dtype=torch.int32, device=d)
+        gemm = lambda a, w, z, s: ops().gptq_gemm(a, w, z, s, e, True, 4, 128, torch.empty(0), torch.empty(0),   # noqa: E731
+                                                  dtype == torch.bfloat16)
+    qz, sc, qz2, sc2 = qz.to(d), sc.to(d), qz2.to(d), sc2.to(d)
+    img = ops().w4a16_prepack(qg, qz, sc, quant == "gptq")
+    img2 = ops().w4a16_prepack(qg2, qz2, sc2, quant == "gptq")
+    assert img.numel() == 2 * ffn * k and img.dtype == dtype
+    gu = gemm(x, qg, qz, sc)
+    assert_bit_exact(ops().w4a16_gemm_prepacked(x, img, 2 * ffn, k), gu, "plain")
+    act = torch.empty(m, ffn, dtype=dtype, device=d)
+    ops().silu_and_mul(act, gu)
+    assert_bit_exact(ops().w4a16_gemm_prepacked(x, img, 2 * ffn, k, silu=True), act, "silu epilogue")
+    down = gemm(act, qg2, qz2, sc2)
+    packed = ops().w4a16_gemm_prepacked(x, img, 2 * ffn, k, silu=True, out_image=True)
+    assert_bit_exact(ops().w4a16_gemm_prepacked(packed, img2, n2, ffn), down, "silu -> image -> down_proj")
+    assert_bit_exact(ops().w4a16_gemm_prepacked(act, img2, n2, ffn), down, "down_proj from row-major act")
+    with pytest.raises(RuntimeError):
+        ops().w4a16_gemm_prepacked(x[:64], img, 2 * ffn, k)          # decode sizes stream the int4 words

@@ -710,6 +710,68 @@ def awq_gemm_packed_a(a: PackedOperand, qweight: torch.Tensor, qzeros: torch.Ten
     return out
 
 
+# ---- weight-load-time image of a w4a16 layer for the prefill GEMM (MI355X-side, no reference op) ----
+PREPACKED_SILU, PREPACKED_OUT_IMAGE, PREPACKED_A_IMAGE = 1, 2, 4
+
+
+def w4a16_prepack(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                  gptq_zeros: bool = False) -> torch.Tensor:
+    """The operand image the prefill GEMM multiplies (T(fma(q, s, -z s)) in MFMA piece order), computed
+    ONCE instead of on every awq_gemm / gptq_gemm call with m >= 1024.  qweight: exllama layout (declared
+    [N, K/8] from awq_to_gptq_4bit, or [K/8, N] from gptq_shuffle).  Returns a flat tensor of N * K
+    elements of scales.dtype (N * K * 2 bytes)."""
+    _dev(qweight, qzeros, scales)
+    n = scales.size(1)
+    k = qweight.numel() * 8 // n
+    group = k // scales.size(0)
+    image = torch.empty(n * k, dtype=scales.dtype, device=scales.device)
+    rc = _abi.load().mi355x_w4a16_prepack(_ptr(image), _ptr(qweight), _ptr(scales), _ptr(qzeros), n, k,
+                                          group, 1 if gptq_zeros else 0, _dt(scales), _stream())
+    _abi.check(rc, "w4a16_prepack")
+    return image
+
+
+def w4a16_gemm_prepacked(a, image: torch.Tensor, n: int, k: int, silu: bool = False,
+                         out_image: bool = False):
+    """a [m, k] (row-major tensor or PackedOperand) times a prepacked weight image (m >= 1024).
+    silu: gate_up projection, returns silu_and_mul(a . W) [m, n/2]; out_image (with silu): returns it
+    as a PackedOperand for the next GEMM.  Bit-identical to awq_gemm (+ silu_and_mul) at the same m."""
+    packed_in = isinstance(a, PackedOperand)
+    data = a.data if packed_in else a
+    _dev(data, image)
+    m = a.m if packed_in else a.shape[0]
+    if (a.k if packed_in else a.shape[1]) != k:
+        raise RuntimeError("w4a16_gemm_prepacked: operand k does not match the image")
+    mode = (PREPACKED_SILU if silu else 0) | (PREPACKED_OUT_IMAGE if out_image else 0) | \
+        (PREPACKED_A_IMAGE if packed_in else 0)
+    m_pad = (m + 15) // 16 * 16
+    ws = None
+    if not packed_in:
+        if a.dim() != 2 or a.stride(1) != 1:
+            raise RuntimeError("w4a16_gemm_prepacked: input must be [M, K] with unit inner stride")
+        ws = _a_scratch(m_pad * k * 2, data.device)
+    if out_image:
+        out = torch.empty(m_pad * (n // 2), dtype=data.dtype, device=data.device)
+    else:
+        out = torch.empty((m, n // 2 if silu else n), dtype=data.dtype, device=data.device)
+    rc = _abi.load().mi355x_w4a16_gemm_prepacked(
+        _ptr(out), _ptr(data), _ptr(image), _ptr(ws), ws.numel() if ws is not None else 0, m, n, k,
+        k if packed_in else a.stride(0), mode, _dt(data), _stream())
+    _abi.check(rc, "w4a16_gemm_prepacked")
+    return PackedOperand(out, m, n // 2) if out_image else out
+
+
+_A_SCRATCH: dict = {}
+
+
+def _a_scratch(nbytes: int, device) -> torch.Tensor:
+    buf = _A_SCRATCH.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _A_SCRATCH[device] = buf
+    return buf
+
+
 def awq_gemm_deferred(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
                       scales: torch.Tensor, temp_space: torch.Tensor):
     """awq_gemm that may leave its split-K reduction to the consumer: returns (out, sk).  sk >= 2:

@@ -186,6 +186,8 @@ struct GemmArgs {
   bool fuse_silu = false;    // prefill gate_up: write silu_and_mul(C) [m, n/2] instead of C
   bool out_packed = false;   // with fuse_silu, m >= 1024: write it as the operand image of the next GEMM
   bool a_packed = false;     // m >= 1024: `a` already is an operand image (pack_a_kernel's format)
+  const void* b_image = nullptr;   // m >= 1024: the weights' operand image, dequantised once at load time
+                                   // (mi355x_w4a16_prepack); qw / scales / qz are then unused
 };
 
 

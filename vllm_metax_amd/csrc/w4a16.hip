@@ -330,6 +330,7 @@ __global__ __launch_bounds__(kSmThreads, 4) void w4a16_gemm_small_m_kernel(
 
 int w4a16_gemm_large_m_dispatch(const GemmArgs& g, int dtype);  // w4a16_large.hip
 int w4a16_gemm_unfused_dispatch(const GemmArgs& g, int dtype);  // w4a16_unfused.hip
+int w4a16_prepack_dispatch(const GemmArgs& g, int dtype);       // w4a16_unfused.hip
 int w4a16_gemm_stripe_dispatch(const GemmArgs& g, int dtype, int row0, int rows);  // w4a16_stripe.hip
 int w4a16_gemm_stripe_silu_dispatch(const GemmArgs& g, int dtype);                  // w4a16_stripe.hip
 
@@ -664,6 +665,51 @@ int mi355x_awq_gemm_packed_a(void* out, const void* a_packed, const uint32_t* qw
                  "awq_gemm_packed_a: needs a 2-byte dtype, m >= 1024, n %% 64 == 0, k %% 32 == 0 and "
                  "dq_workspace >= (n + roundup(m,16))*k*2 bytes; got m=%d n=%d k=%d, %lld bytes",
                  m, n, k, (long long)dq_workspace_bytes);
+  return rc;
+}
+
+int mi355x_w4a16_prepack(void* image, const uint32_t* qweight, const void* scales,
+                         const uint32_t* qzeros, int n, int k, int group_size, int gptq_zeros, int dtype,
+                         mi355x_stream stream) {
+  MI355X_REQUIRE(n > 0 && k > 0 && group_size > 0 && n % 64 == 0 && k % 32 == 0 &&
+                     group_size % 32 == 0 && k % group_size == 0,
+                 MI355X_EUNSUPPORTED, "w4a16_prepack: needs n %% 64 == 0, k %% 32 == 0, group %% 32 == 0 "
+                 "(n=%d k=%d group=%d)", n, k, group_size);
+  MI355X_REQUIRE(image && qweight && scales && qzeros, MI355X_EINVAL, "w4a16_prepack: null pointer");
+  MI355X_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, MI355X_EINVAL,
+                 "w4a16_prepack: image must be 16-byte aligned");
+  GemmArgs g{image, nullptr, qweight, scales, qzeros, nullptr, 0, nullptr, 0, 0, n, k, group_size, 0,
+             gptq_zeros ? kZeroGptq : kZeroAwq, static_cast<hipStream_t>(stream)};
+  const int rc = w4a16_prepack_dispatch(g, dtype);
+  MI355X_REQUIRE(rc != 1, MI355X_EUNSUPPORTED, "w4a16_prepack: needs a 2-byte dtype");
+  return rc;
+}
+
+int mi355x_w4a16_gemm_prepacked(void* out, const void* a, const void* image, void* a_workspace,
+                                int64_t a_workspace_bytes, int m, int n, int k, int64_t lda, int mode,
+                                int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(m >= 0 && n > 0 && k > 0 && n % 64 == 0 && k % 32 == 0, MI355X_EUNSUPPORTED,
+                 "w4a16_gemm_prepacked: bad sizes m=%d n=%d k=%d", m, n, k);
+  if (m == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && a && image, MI355X_EINVAL, "w4a16_gemm_prepacked: null pointer");
+  const bool silu = mode & MI355X_PREPACKED_SILU, outp = mode & MI355X_PREPACKED_OUT_IMAGE,
+             ain = mode & MI355X_PREPACKED_A_IMAGE;
+  MI355X_REQUIRE(!outp || silu, MI355X_EINVAL, "w4a16_gemm_prepacked: OUT_IMAGE needs SILU");
+  GemmArgs g{out, a, nullptr, nullptr, nullptr, nullptr, 0, a_workspace, a_workspace_bytes, m, n, k,
+             32, ain ? (int64_t)k : lda, kZeroAwq, static_cast<hipStream_t>(stream)};
+  g.fuse_silu = silu;
+  g.out_packed = outp;
+  g.a_packed = ain;
+  g.b_image = image;
+  if (!ain) {
+    MI355X_REQUIRE(lda % 8 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0, MI355X_EUNSUPPORTED,
+                   "w4a16_gemm_prepacked: activations must be 16-byte aligned with lda %% 8 == 0");
+  }
+  const int rc = w4a16_gemm_unfused_dispatch(g, dtype);
+  MI355X_REQUIRE(rc != 1, MI355X_EUNSUPPORTED,
+                 "w4a16_gemm_prepacked: needs a 2-byte dtype, m >= 1024 (n %% 256 == 0 with SILU) and an "
+                 "activation workspace of roundup(m,16)*k*2 bytes (got m=%d n=%d k=%d, %lld bytes)",
+                 m, n, k, (long long)a_workspace_bytes);
   return rc;
 }
 

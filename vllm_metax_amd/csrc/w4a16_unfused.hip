@@ -279,11 +279,8 @@ static inline int64_t unfused_scratch_bytes(int m, int n, int k) {
   return ((int64_t)n + m_pad) * k * 2;
 }
 
-template <typename T, int MODE>
-static int run_unfused(const GemmArgs& g) {
-  constexpr bool SILU = MODE != 0;
-  T* packed_b = static_cast<T*>(g.dq_ws);
-  const T* packed_a = packed_b + (int64_t)g.n * g.k;
+template <typename T>
+static int launch_dequant_pack(const GemmArgs& g, T* packed_b) {
   const int64_t words = (int64_t)(g.k / 32) * g.n;   // one thread per (column, 32-k step)
   if (g.zmode == kZeroAwq) {
     hipLaunchKernelGGL((w4_dequant_pack_kernel<T, kZeroAwq>), dim3((words + 255) / 256), dim3(256), 0,
@@ -294,15 +291,41 @@ static int run_unfused(const GemmArgs& g) {
                        g.stream, packed_b, g.qw, static_cast<const T*>(g.scales), g.qz, g.n, g.k,
                        g.group);
   }
-  int rc = check_launch("w4_dequant_pack");
-  if (rc) return rc;
+  return check_launch("w4_dequant_pack");
+}
+
+// mi355x_w4a16_prepack: the weights' operand image, once (weight-load time)
+int w4a16_prepack_dispatch(const GemmArgs& g, int dtype) {
+  if (g.k % kUfBK != 0 || g.n % 64 != 0) return 1;
+  if (dtype == MI355X_BF16) return launch_dequant_pack<bf16_t>(g, static_cast<bf16_t*>(g.c));
+  if (dtype == MI355X_F16) return launch_dequant_pack<f16_t>(g, static_cast<f16_t*>(g.c));
+  return 1;
+}
+
+template <typename T, int MODE>
+static int run_unfused(const GemmArgs& g) {
+  constexpr bool SILU = MODE != 0;
+  // scratch: [weight image (absent when the caller holds a prepacked one)] [activation image]
+  T* scratch = static_cast<T*>(g.dq_ws);
+  const T* packed_b;
+  T* packed_a_dst;
+  int rc;
+  if (g.b_image != nullptr) {
+    packed_b = static_cast<const T*>(g.b_image);
+    packed_a_dst = scratch;
+  } else {
+    rc = launch_dequant_pack<T>(g, scratch);
+    if (rc) return rc;
+    packed_b = scratch;
+    packed_a_dst = scratch + (int64_t)g.n * g.k;
+  }
+  const T* packed_a = packed_a_dst;
   if (g.a_packed) {
     packed_a = static_cast<const T*>(g.a);   // the producer already wrote the operand image
   } else {
     const int m_tiles = (g.m + 15) / 16;
     hipLaunchKernelGGL(pack_a_kernel<T>, dim3((g.k + kPackK - 1) / kPackK, m_tiles), dim3(256), 0,
-                       g.stream, packed_b + (int64_t)g.n * g.k, static_cast<const T*>(g.a), g.m, g.k,
-                       g.lda);
+                       g.stream, packed_a_dst, static_cast<const T*>(g.a), g.m, g.k, g.lda);
     rc = check_launch("pack_a");
     if (rc) return rc;
   }
@@ -330,8 +353,14 @@ static int run_unfused(const GemmArgs& g) {
 
 // returns 1 when not applicable (caller uses the fused kernel)
 int w4a16_gemm_unfused_dispatch(const GemmArgs& g, int dtype) {
-  if (g.dq_ws == nullptr) return 1;
-  if (g.dq_ws_bytes < unfused_scratch_bytes(g.m, g.n, g.k)) return 1;
+  if (g.b_image != nullptr) {
+    // prepacked weights: the scratch only holds the activation image (none when `a` is one already)
+    const int64_t need = g.a_packed ? 0 : (((int64_t)g.m + 15) / 16 * 16) * g.k * 2;
+    if (need > 0 && (g.dq_ws == nullptr || g.dq_ws_bytes < need)) return 1;
+  } else {
+    if (g.dq_ws == nullptr) return 1;
+    if (g.dq_ws_bytes < unfused_scratch_bytes(g.m, g.n, g.k)) return 1;
+  }
   if (g.k % kUfBK != 0 || g.n % 64 != 0) return 1;
   if (g.m < 1024) return 1;   // too few 256-row tiles to fill 256 CUs below that
   if (g.fuse_silu) {

@@ -126,6 +126,19 @@ class QLinear:
 
     _shared_ws = {}   # device -> fp32 split-K scratch shared by every layer (stream-ordered use)
     packed_silu = os.environ.get("MI355X_PACKED_SILU", "1") != "0"   # A/B switch for the bench
+    # keep the prefill GEMM's weight operand image (dequantised once at load time, n*k*2 bytes per
+    # layer: 14 GB for Llama-3-8B of the 288 GB) instead of re-deriving it from the int4 words on every
+    # prefill call; decode still streams the int4 words.  MI355X_PREPACK=0 switches it off.
+    prepack = os.environ.get("MI355X_PREPACK", "1") != "0"
+
+    def image(self):
+        """The prefill GEMM's weight image (None when not applicable), built on first use."""
+        if not self.prepack or self.quant not in ("awq", "gptq") or self.dtype == torch.float32 \
+                or self.n % 64 or self.k % 32:
+            return None
+        if getattr(self, "_image", None) is None:
+            self._image = ops.w4a16_prepack(self.qweight, self.qzeros, self.scales, self.quant == "gptq")
+        return self._image
 
     def _workspace(self, m: int, device):
         """fp32 scratch for the split-K partial slabs of the decode GEMM: up to 8 slabs of
@@ -140,6 +153,8 @@ class QLinear:
 
     def __call__(self, x) -> torch.Tensor:
         m = x.shape[0]
+        if m >= 1024 and self.image() is not None:
+            return ops.w4a16_gemm_prepacked(x, self.image(), self.n, self.k)
         if isinstance(x, ops.PackedOperand):     # prefill: activations already re-tiled by the producer
             return ops.awq_gemm_packed_a(x, self.qweight, self.qzeros, self.scales)
         if self.quant == "awq":
@@ -166,6 +181,9 @@ class QLinear:
 
     def silu_mul(self, x: torch.Tensor):
         """silu_and_mul(self(x)) in one launch where the library supports it (AWQ, M >= 1024), else None."""
+        if x.shape[0] >= 1024 and self.n % 256 == 0 and self.image() is not None:
+            return ops.w4a16_gemm_prepacked(x, self.image(), self.n, self.k, silu=True,
+                                            out_image=self.packed_silu)
         if self.quant == "awq":
             if x.shape[0] >= 1024 and self.packed_silu:
                 # the result goes straight into the operand image of the next (down_proj) GEMM
