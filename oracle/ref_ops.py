@@ -541,6 +541,36 @@ def gptq_gemm(x, qweight_shuffled, qzeros, scales, g_idx_perm, group_size) -> to
     return (xx.double() @ wd.double()).to(x.dtype)
 
 
+def gptq8_unpack_rows(qweight: torch.Tensor) -> np.ndarray:
+    """8-bit GPTQ qweight [K/4, N]: byte i of word (kk, n) = W[4kk + i, n] (the exllama 8-bit shuffle is
+    the identity: csrc/quantization/gptq/qdq_8.cuh:14)."""
+    w = qweight.numpy().view(np.uint32)[..., None]
+    b = ((w >> (8 * np.arange(4, dtype=np.uint32))) & 0xFF).astype(np.uint8)        # [K/4, N, 4]
+    return b.transpose(0, 2, 1).reshape(-1, b.shape[1])
+
+
+def gptq8_pack_rows(w: np.ndarray) -> torch.Tensor:
+    k, n = w.shape
+    b = w.reshape(k // 4, 4, n).astype(np.uint32)
+    out = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16) | (b[:, 3] << 24)
+    return torch.from_numpy(out.view(np.int32))
+
+
+def gptq8_gemm(x, qweight, qzeros, scales, group_size) -> torch.Tensor:
+    """gptq_gemm with bit = 8 (csrc/quantization/gptq/q_gemm.cu:1998-2003, hgemm_gptq.h:892-899): the
+    reference's fast path fixes the zero at 128 (kU8B128: zs = -128 * s); the generic exllama path uses
+    qzeros + 1 (q_gemm.cu:688).  They agree on symmetric checkpoints (stored zero 127); like the 4-bit
+    path this oracle — and the build — uses qzeros + 1.  qzeros [K/g, N/4], byte i of word j = column
+    4j + i.  parity unpinned (no numeric reference test exists for gptq_gemm)."""
+    w = gptq8_unpack_rows(qweight).astype(np.int32)
+    zb = qzeros.numpy().view(np.uint32)[..., None]
+    z = ((zb >> (8 * np.arange(4, dtype=np.uint32))) & 0xFF).astype(np.int32).reshape(qzeros.shape[0], -1) + 1
+    zz = np.repeat(z, group_size, axis=0)[:w.shape[0]]
+    s = scales.float().repeat_interleave(group_size, dim=0)[:w.shape[0]]
+    wd = (torch.from_numpy(w - zz).float() * s).to(scales.dtype)
+    return (x.double() @ wd.double()).to(x.dtype)
+
+
 # ============================================================================ fp8 GEMM
 def scaled_mm_fp8(a, b, a_scales, b_scales, out_dtype, bias=None) -> torch.Tensor:
     """Behind the schema cutlass_scaled_mm (csrc/torch_bindings.cpp:251-256).  The

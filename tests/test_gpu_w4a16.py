@@ -336,3 +336,29 @@ def test_prepacked_weight_image_is_bit_identical(dtype, quant):
     assert_bit_exact(ops().w4a16_gemm_prepacked(act, img2, n2, ffn), down, "down_proj from row-major act")
     with pytest.raises(RuntimeError):
         ops().w4a16_gemm_prepacked(x[:64], img, 2 * ffn, k)          # decode sizes stream the int4 words
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,n", [(1, 256, 128), (33, 1024, 320), (64, 4096, 512), (100, 512, 64), (1100, 512, 256)])
+@pytest.mark.parametrize("sym", [True, False])
+def test_gptq_gemm_8bit(dtype, m, k, n, sym):
+    """gptq_gemm bit = 8 (q_gemm.cu:1998-2003): zero = qzeros + 1 (= the fast path's fixed 128 on symmetric
+    checkpoints, stored zero 127); gptq_shuffle with bit 8 leaves the words as they are (qdq_8.cuh:14)."""
+    rng = np.random.default_rng(7)
+    group = 128
+    w = rng.integers(0, 256, size=(k, n), dtype=np.uint8)
+    z = np.full((k // group, n), 127, dtype=np.uint8) if sym else rng.integers(0, 255, size=(k // group, n), dtype=np.uint8)
+    zb = z.reshape(k // group, n // 4, 4).astype(np.uint32)
+    qz = torch.from_numpy((zb[..., 0] | (zb[..., 1] << 8) | (zb[..., 2] << 16) | (zb[..., 3] << 24)).view(np.int32))
+    qw = R.gptq8_pack_rows(w)
+    sc = (torch.rand(k // group, n, generator=torch.Generator().manual_seed(1)) * 4e-4 + 1e-4).to(dtype)
+    x = (torch.randn(m, k, generator=torch.Generator().manual_seed(2)) * 0.5).to(dtype)
+    ref = R.gptq8_gemm(x, qw, qz, sc, group)
+    d = dev()
+    qd = qw.to(d)
+    before = qd.clone()
+    ops().gptq_shuffle(qd, torch.empty(0, dtype=torch.int32), 8)
+    assert torch.equal(qd, before)
+    out = ops().gptq_gemm(x.to(d), qd, qz.to(d), sc.to(d), torch.empty(0, dtype=torch.int32, device=d), True, 8,
+                          group, torch.empty(0), torch.empty(0), dtype == torch.bfloat16)
+    _check_gemm(out, ref, f"gptq 8-bit {m}x{n}x{k}")

@@ -43,9 +43,35 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def _dev(*ts: Optional[torch.Tensor]) -> None:
+    """Every tensor on the GPU, and on the CURRENT device: the C-ABI launches on torch's current stream,
+    which belongs to the current device (torch_bindings.cpp has a device guard for the same reason)."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("expected a tensor on the GPU (hip) device, got " + str(t.device))
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(f"tensor on {t.device} but the current device is cuda:{cur}: wrap the call in "
+                               f"torch.cuda.device({t.device.index})")
+
+
+_RETIRED: list = []   # scratch buffers that were outgrown: kept alive, a captured HIP graph may still use them
+
+
+def _grow(table: dict, key, nbytes_or_elems: int, dtype) -> torch.Tensor:
+    """Per-device scratch, grown on demand.  An outgrown buffer is retired, not freed: a HIP graph
+    captured earlier keeps launching kernels that write to its address (scratch contents never outlive
+    a call, so the only hazard would be the allocator handing that memory to somebody else)."""
+    buf = table.get(key)
+    if buf is None or buf.numel() < nbytes_or_elems:
+        if buf is not None:
+            _RETIRED.append(buf)
+        buf = torch.empty(nbytes_or_elems, dtype=dtype, device=key)
+        table[key] = buf
+    return buf
 
 
 def _kv_dtype(kv_cache_dtype: str, cache: torch.Tensor, k_scale, v_scale):
@@ -506,11 +532,7 @@ def _dq_scratch(m: int, n: int, k: int, device) -> Optional[torch.Tensor]:
         return None
     else:
         need = (n + m_pad) * k * 2              # prefill: packed weights + packed activations
-    buf = _DQ_SCRATCH.get(device)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(need, dtype=torch.uint8, device=device)
-        _DQ_SCRATCH[device] = buf
-    return buf
+    return _grow(_DQ_SCRATCH, device, need, torch.uint8)
 
 
 def awq_to_gptq_4bit(qweight: torch.Tensor) -> torch.Tensor:
@@ -765,11 +787,7 @@ _A_SCRATCH: dict = {}
 
 
 def _a_scratch(nbytes: int, device) -> torch.Tensor:
-    buf = _A_SCRATCH.get(device)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _A_SCRATCH[device] = buf
-    return buf
+    return _grow(_A_SCRATCH, device, nbytes, torch.uint8)
 
 
 def awq_gemm_deferred(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor,
@@ -823,6 +841,8 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Te
         raise RuntimeError("gptq_gemm: a must be contiguous")
     m, k = a.shape
     n = b_q_weight.size(1)
+    if group_size == -1:          # per-channel GPTQ: one group spanning K
+        group_size = k
     g_idx = None
     if b_g_idx is not None and b_g_idx.device.type != "meta" and b_g_idx.numel() > 0:
         g_idx = b_g_idx.to(torch.int32).contiguous()
@@ -882,11 +902,7 @@ _F32_SCRATCH = {}
 
 def _scratch_f32(elems: int, device) -> torch.Tensor:
     """Per-device reusable fp32 scratch (stream-ordered use), grown on demand."""
-    t = _F32_SCRATCH.get(device)
-    if t is None or t.numel() < elems:
-        t = torch.empty(elems, dtype=torch.float32, device=device)
-        _F32_SCRATCH[device] = t
-    return t
+    return _grow(_F32_SCRATCH, device, elems, torch.float32)
 
 
 def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:

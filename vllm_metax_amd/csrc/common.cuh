@@ -35,6 +35,19 @@ int check_launch(const char* what);
     }                                    \
   } while (0)
 
+// One-time per-DEVICE setup of a kernel (hipFuncSetAttribute is a per-device property): a bit per
+// device ordinal.  The header promises "no global state": this is a cache of a fact about the device,
+// not state of a call; setting the attribute twice (two threads racing) is harmless.
+struct PerDeviceOnce {
+  unsigned long long done = 0;
+  bool need(int* dev) {
+    *dev = 0;
+    (void)hipGetDevice(dev);
+    return ((done >> (*dev & 63)) & 1ull) == 0;
+  }
+  void mark(int dev) { done |= 1ull << (dev & 63); }
+};
+
 // ---- asynchronous global -> LDS copies (LDS-DMA) -----------------------------------------
 // One wave copies 64 x 16 B: lane l reads 16 B at `gptr` (per lane) and the hardware writes
 // them at LDS byte address lds_base + 16 * l (lds_base is wave-uniform, in M0).

@@ -564,8 +564,9 @@ static int run_fp8(const Fp8Args& g) {
       const int num_m_blocks = (g.m + 255) / 256, num_n_blocks = (g.n + 255) / 256;
       const int num_tiles = num_m_blocks * num_n_blocks;
       const size_t smem = (size_t)4 * 2048 * sizeof(uint4);   // 128 KiB in either ring shape
-      auto launch = [&](auto kern, bool& attr_set) -> int {
-        if (!attr_set) {
+      auto launch = [&](auto kern, PerDeviceOnce& once) -> int {
+        int dev;
+        if (once.need(&dev)) {
           hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
           if (e != hipSuccess) {
@@ -573,7 +574,7 @@ static int run_fp8(const Fp8Args& g) {
                       hipGetErrorString(e));
             return MI355X_EUNSUPPORTED;
           }
-          attr_set = true;
+          once.mark(dev);
         }
         hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(512), smem, g.stream, out,
                            reinterpret_cast<const uint4*>(pa), reinterpret_cast<const uint4*>(pb),
@@ -581,7 +582,7 @@ static int run_fp8(const Fp8Args& g) {
                            num_m_blocks, num_tiles);
         return 0;
       };
-      static bool attr[4] = {false, false, false, false};
+      static PerDeviceOnce attr[4];   // per kernel variant, one bit per device
       bool wide = false;
       if constexpr (Op::kWide) wide = g.k % 128 == 0;
       if constexpr (Op::kWide) {

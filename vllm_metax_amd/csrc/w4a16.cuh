@@ -186,6 +186,8 @@ struct GemmArgs {
   bool fuse_silu = false;    // prefill gate_up: write silu_and_mul(C) [m, n/2] instead of C
   bool out_packed = false;   // with fuse_silu, m >= 1024: write it as the operand image of the next GEMM
   bool a_packed = false;     // m >= 1024: `a` already is an operand image (pack_a_kernel's format)
+  int bits = 4;              // 8: GPTQ 8-bit (words [K/4][N], byte i of word (kk, n) = W[4kk + i][n], qzeros
+                             // [K/g][N/4], zero = qzeros + 1; q_gemm.cu:1998-2003 kU8B128 on symmetric files)
   const void* b_image = nullptr;   // m >= 1024: the weights' operand image, dequantised once at load time
                                    // (mi355x_w4a16_prepack); qw / scales / qz are then unused
 };

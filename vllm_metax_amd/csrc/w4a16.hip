@@ -458,8 +458,62 @@ __global__ __launch_bounds__(256) void w4a16_gemm_any_n_kernel(
   }
 }
 
+// 8-bit GPTQ, any shape: same structure (16 columns x 8 rows per workgroup, 16 k-parts), 4 k per word.
+// Decode-sized 8-bit GEMMs run here: a correctness path (the int4 stripe kernel has no 8-bit twin;
+// m >= 1024 goes through the operand-image GEMM).
+template <typename T>
+__global__ __launch_bounds__(256) void w8a16_gemm_any_kernel(
+    T* __restrict__ c, const T* __restrict__ a, const uint32_t* __restrict__ qw,
+    const T* __restrict__ scales, const uint32_t* __restrict__ qz, int m, int n, int k, int group,
+    int64_t lda) {
+  __shared__ float red[16][8][17];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int kp = threadIdx.x >> 4;
+  const int row0 = blockIdx.y * 8;
+  float acc[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+  if (col < n) {
+    for (int kk = kp; kk < k / 4; kk += 16) {
+      const int g = (kk * 4) / group;
+      const uint32_t w = qw[(int64_t)kk * n + col];
+      const float s = to_f32(scales[(int64_t)g * n + col]);
+      const float z = (float)(((qz[(int64_t)g * (n >> 2) + (col >> 2)] >> (8 * (col & 3))) & 0xFFu) + 1u);
+      float wv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wv[j] = to_f32(from_f32<T>(fmaf((float)((w >> (8 * j)) & 0xFFu), s, -z * s)));
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (row0 + r < m) {
+          const T* ap = a + (int64_t)(row0 + r) * lda + kk * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[r] = fmaf(to_f32(ap[j]), wv[j], acc[r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) red[kp][r][threadIdx.x & 15] = acc[r];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int r = threadIdx.x >> 4, cc = threadIdx.x & 15;
+    float sum = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) sum += red[p][r][cc];
+    const int oc = blockIdx.x * 16 + cc;
+    if (row0 + r < m && oc < n) c[(int64_t)(row0 + r) * n + oc] = from_f32<T>(sum);
+  }
+}
+
 template <typename T>
 static int launch_any_n(const GemmArgs& g) {
+  if (g.bits == 8) {
+    dim3 grid8((g.n + 15) / 16, (g.m + 7) / 8), block8(256);
+    hipLaunchKernelGGL(w8a16_gemm_any_kernel<T>, grid8, block8, 0, g.stream, static_cast<T*>(g.c),
+                       static_cast<const T*>(g.a), g.qw, static_cast<const T*>(g.scales), g.qz, g.m, g.n,
+                       g.k, g.group, g.lda);
+    return check_launch("w8a16_gemm_any");
+  }
   dim3 grid((g.n + 15) / 16, (g.m + 7) / 8), block(256);
   if (g.zmode == kZeroAwq) {
     hipLaunchKernelGGL((w4a16_gemm_any_n_kernel<T, kZeroAwq>), grid, block, 0, g.stream,
@@ -478,6 +532,13 @@ static int run_gemm_t(const GemmArgs& g, int dtype) {
   if (g.n % 64 != 0) {
     MI355X_REQUIRE(g.defer_sk == nullptr && !g.fuse_silu && !g.a_packed, MI355X_EUNSUPPORTED,
                    "w4a16 gemm: the fused / deferred forms need n %% 64 == 0 (n = %d)", g.n);
+    return launch_any_n<T>(g);
+  }
+  if (g.bits == 8) {
+    if (g.m >= 1024) {
+      int rc = w4a16_gemm_unfused_dispatch(g, dtype);
+      if (rc != 1) return rc;
+    }
     return launch_any_n<T>(g);
   }
   if (g.m >= 1024) {
@@ -718,11 +779,12 @@ int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,
                      void* perm_space, float* workspace, int64_t workspace_elems,
                      void* dq_workspace, int64_t dq_workspace_bytes, int m, int n, int k, int bit,
                      int group_size, int dtype, mi355x_stream stream) {
-  MI355X_REQUIRE(bit == 4, MI355X_EUNSUPPORTED,
-                 "gptq_gemm: only 4-bit weights are implemented (bit=%d)", bit);
+  MI355X_REQUIRE(bit == 4 || bit == 8, MI355X_EUNSUPPORTED,
+                 "gptq_gemm: 4-bit and 8-bit weights are implemented (bit=%d)", bit);
   GemmArgs g{c, a, qweight, scales, qzeros, workspace, workspace_elems, dq_workspace,
              dq_workspace_bytes, m, n, k, group_size, k, kZeroGptq,
              static_cast<hipStream_t>(stream)};
+  g.bits = bit;
   int rc = validate_gemm(g, "gptq_gemm");
   if (rc || m == 0) return rc;
   if (g_idx) {

@@ -458,8 +458,9 @@ template <typename T, int MT, int NW, int ZMODE, int SETS, bool SILU = false>
 static int launch_stripe_cfg(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p) {
   using Cfg = StripeCfg<MT, NW, SETS>;
   auto kern = w4a16_gemm_stripe_kernel<T, MT, NW, ZMODE, SETS, SILU>;
-  static bool attr_set = false;  // one per instantiation
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;  // one per instantiation, one bit per device
+  int dev;
+  if (attr_once.need(&dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
     if (e != hipSuccess) {
@@ -467,7 +468,7 @@ static int launch_stripe_cfg(const GemmArgs& g, const T* a, T* c, int rows, cons
                 hipGetErrorString(e));
       return MI355X_EUNSUPPORTED;
     }
-    attr_set = true;
+    attr_once.mark(dev);
   }
   const int stripes = SILU ? g.n / 128 : (g.n + Cfg::BN - 1) / Cfg::BN;
   hipLaunchKernelGGL(kern, dim3(stripes, p.sk), dim3(kStThreads), Cfg::LDS_BYTES, g.stream, c, g.ws,

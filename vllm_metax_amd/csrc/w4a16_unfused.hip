@@ -60,6 +60,39 @@ __global__ __launch_bounds__(256) void w4_dequant_pack_kernel(
   for (int lr = 0; lr < 4; ++lr) piece[frag_swz(lr, c)] = dequant_word<T>(w[lr], s, zs);
 }
 
+// 8-bit GPTQ weights (words [K/4][N], 4 consecutive k of one column per word, zero = qzeros + 1):
+// same image, one thread per (column, 32-k step) reads 8 words.
+template <typename T>
+__global__ __launch_bounds__(256) void w8_dequant_pack_kernel(
+    T* __restrict__ packed, const uint32_t* __restrict__ qw, const T* __restrict__ scales,
+    const uint32_t* __restrict__ qz, int n, int k, int group) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int kt32 = k >> 5;
+  if (idx >= (int64_t)kt32 * n) return;
+  const int kt = (int)(idx / n);
+  const int col = (int)(idx - (int64_t)kt * n);
+  const int g = (kt * 32) / group;
+  const float s = to_f32(scales[(int64_t)g * n + col]);
+  const float z = (float)(((qz[(int64_t)g * (n >> 2) + (col >> 2)] >> (8 * (col & 3))) & 0xFFu) + 1u);
+  const float zs = -z * s;
+  const int q = col >> 6, c = (col & 63) >> 2, t = col & 3;
+  const int nt = q * 4 + t;
+  uint4* piece = reinterpret_cast<uint4*>(packed) + ((int64_t)nt * kt32 + kt) * 64;
+#pragma unroll
+  for (int lr = 0; lr < 4; ++lr) {
+    const uint32_t w0 = qw[(int64_t)(kt * 8 + 2 * lr) * n + col];
+    const uint32_t w1 = qw[(int64_t)(kt * 8 + 2 * lr + 1) * n + col];
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[j] = fmaf((float)((w0 >> (8 * j)) & 0xFFu), s, zs);
+      f[4 + j] = fmaf((float)((w1 >> (8 * j)) & 0xFFu), s, zs);
+    }
+    piece[frag_swz(lr, c)] = make_uint4(Mfma<T>::pack(f[0], f[1]), Mfma<T>::pack(f[2], f[3]),
+                                        Mfma<T>::pack(f[4], f[5]), Mfma<T>::pack(f[6], f[7]));
+  }
+}
+
 // (kernel 2, pack_a_kernel: activations -> operand images, lives in w4a16.cuh)
 
 // ---------------------------------------------------------------- kernel 3: the GEMM
@@ -282,6 +315,11 @@ static inline int64_t unfused_scratch_bytes(int m, int n, int k) {
 template <typename T>
 static int launch_dequant_pack(const GemmArgs& g, T* packed_b) {
   const int64_t words = (int64_t)(g.k / 32) * g.n;   // one thread per (column, 32-k step)
+  if (g.bits == 8) {
+    hipLaunchKernelGGL(w8_dequant_pack_kernel<T>, dim3((words + 255) / 256), dim3(256), 0, g.stream,
+                       packed_b, g.qw, static_cast<const T*>(g.scales), g.qz, g.n, g.k, g.group);
+    return check_launch("w8_dequant_pack");
+  }
   if (g.zmode == kZeroAwq) {
     hipLaunchKernelGGL((w4_dequant_pack_kernel<T, kZeroAwq>), dim3((words + 255) / 256), dim3(256), 0,
                        g.stream, packed_b, g.qw, static_cast<const T*>(g.scales), g.qz, g.n, g.k,
@@ -335,15 +373,16 @@ static int run_unfused(const GemmArgs& g) {
   const int num_tiles = num_m_blocks * num_n_blocks;
   const size_t smem = (size_t)kUfStages * 2048 * sizeof(uint4);  // 128 KiB
   auto kern = gemm_packed_kernel<T, MODE>;
-  static bool attr_set = false;  // one flag per instantiation (T, MODE)
-  if (!attr_set) {
+  static PerDeviceOnce attr_once;  // one per instantiation (T, MODE), one bit per device
+  int dev;
+  if (attr_once.need(&dev)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) {
       set_error("gemm_packed: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
       return MI355X_EUNSUPPORTED;
     }
-    attr_set = true;
+    attr_once.mark(dev);
   }
   hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(kUfThreads), smem, g.stream, static_cast<T*>(g.c),
                      reinterpret_cast<const uint4*>(packed_a), reinterpret_cast<const uint4*>(packed_b),

@@ -125,6 +125,7 @@ class QLinear:
         self._ws = {}
 
     _shared_ws = {}   # device -> fp32 split-K scratch shared by every layer (stream-ordered use)
+    _retired = []     # outgrown scratch buffers, kept alive for graphs captured before the growth
     packed_silu = os.environ.get("MI355X_PACKED_SILU", "1") != "0"   # A/B switch for the bench
     # keep the prefill GEMM's weight operand image (dequantised once at load time, n*k*2 bytes per
     # layer: 14 GB for Llama-3-8B of the 288 GB) instead of re-deriving it from the int4 words on every
@@ -147,6 +148,8 @@ class QLinear:
         need = 8 * m * self.n
         ws = QLinear._shared_ws.get(device)
         if ws is None or ws.numel() < need:
+            if ws is not None:
+                QLinear._retired.append(ws)      # a captured decode graph may still write to it
             ws = torch.zeros(need, dtype=torch.float32, device=device)
             QLinear._shared_ws[device] = ws
         return ws
@@ -290,6 +293,10 @@ class HotPathModel:
         self._graph = None
         self.graph_error = None
         self.collectives_always = False
+        # prefill through the decode fusion kernel (rotary + cache write in one launch): measured SLOWER
+        # at 8192 tokens (96 us vs 29.9 + 19.1 us: its V scatter is per token, reshape_and_cache's is a
+        # 16-token tile transposed through LDS) -> off; bench 5585 vs 5639 tokens/s (profiles/r02 notes)
+        self.fuse_prefill_rope = os.environ.get("MI355X_PREFILL_ROPE_FUSION", "0") != "0"
 
     # ---------------------------------------------------------------- helpers
     def _collectives(self) -> bool:
@@ -327,6 +334,12 @@ class HotPathModel:
             qkv, slabs, sk = L.qkv.deferred(h)
             ops.qkv_rope_cache(qkv, slabs, sk, positions, self.cos_sin, self.k_cache[i],
                                self.v_cache[i], slots, L.q_heads, L.kv_heads, cfg.head_dim)
+            q = qkv[:, :L.q_size]
+        elif self.fuse_prefill_rope and x.dtype != torch.float32 and self.kv_dtype == "auto":
+            # prefill: rotary + cache write in one launch as well (the decode kernel, no slabs)
+            qkv = L.qkv(h)
+            ops.qkv_rope_cache(qkv, None, 0, positions, self.cos_sin, self.k_cache[i], self.v_cache[i],
+                               slots, L.q_heads, L.kv_heads, cfg.head_dim)
             q = qkv[:, :L.q_size]
         else:
             qkv = L.qkv(h)
