@@ -449,14 +449,14 @@ def main():
     roofs = sorted((roof(n, d) for n, d in agg.items()), key=lambda r: -r["total_ms"])
     # HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of
     # the same kernels at the same shapes; a counter pass cannot run inside the timed region)
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
     if os.path.exists(tpath) and args.model == "llama-3-8b" and tp == 1 and args.kv_cache_dtype == "auto":
         with open(tpath) as f:
             traffic = json.load(f)
         for r in roofs:
             if r["kernel"] in traffic:
                 r["traffic"] = traffic[r["kernel"]]
-                r["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_fetch_write.txt)"
+                r["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_summary.txt)"
     if args.kernel_stats and rank == 0:
         for r in roofs:
             print(json.dumps(r), file=sys.stderr)

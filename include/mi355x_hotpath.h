@@ -161,6 +161,8 @@ int mi355x_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
  * the SAME x-split paged cache (the new tokens were already written by
  * reshape_and_cache).  q/out [total_q, num_heads, head_size] packed by
  * cu_seqlens_q int32 [num_seqs+1]; seq_lens int32 [num_seqs] = context + new.
+ * sliding_window W > 0: a query sees only its last W keys (the call site's window_size = (W-1, 0));
+ * softcap c > 0: scores become c * tanh(s / c) before the mask; 0 = off (both run a general kernel).
  * ref (call site, third-party kernel): vllm_metax/v1/attention/backends/
  *      flash_attn.py:725-747; semantic oracle tests/kernels/attention/
  *      test_flash_attn.py:27-80. */
@@ -173,7 +175,8 @@ int mi355x_paged_prefill_attention(void* out, const void* query, const void* key
                                    int64_t q_stride, int64_t out_stride,
                                    int64_t kv_block_stride, int64_t kv_head_stride,
                                    int dtype, int kv_cache_dtype, const float* k_scale,
-                                   const float* v_scale, mi355x_stream stream);
+                                   const float* v_scale, int sliding_window, float softcap,
+                                   mi355x_stream stream);
 
 /* ------------------------------------------------------------- layernorm --
  * ref: csrc/layernorm_kernels.cu:141-162 (rms_norm), :174-217 (fused_add). */
@@ -242,6 +245,16 @@ int mi355x_rotary_embedding(const int64_t* positions, void* query, void* key,
                             int64_t head_stride, int num_heads, int num_kv_heads,
                             int head_size, int is_neox, int dtype,
                             mi355x_stream stream);
+/* batched_rotary_embedding (several LoRA rope tables stacked in one cache): row = positions[t] +
+ * cos_sin_cache_offsets[t]; rot_dim is passed explicitly as in the reference schema.
+ * ref: csrc/pos_encoding_kernels.cu:102-129 (kernel), :219-306 (launcher), schema torch_bindings.cpp:224-229. */
+int mi355x_batched_rotary_embedding(const int64_t* positions, void* query, void* key,
+                                    const void* cos_sin_cache,
+                                    const int64_t* cos_sin_cache_offsets, int num_tokens,
+                                    int rot_dim, int64_t query_stride, int64_t key_stride,
+                                    int64_t head_stride, int num_heads, int num_kv_heads,
+                                    int head_size, int is_neox, int dtype, mi355x_stream stream);
+
 
 /* -------------------------------------------------------------- activation --
  * out[t, :d] = silu(in[t, :d]) * in[t, d:2d].

@@ -203,7 +203,7 @@ def paged_attention_v2(query, key_cache, value_cache, num_kv_heads, scale, block
 
 
 def paged_prefill_attention(query, key_cache, value_cache, num_kv_heads, scale, block_tables,
-                            seq_lens, cu_seqlens_q) -> torch.Tensor:
+                            seq_lens, cu_seqlens_q, sliding_window=None, softcap=None) -> torch.Tensor:
     """Varlen causal (bottom-right aligned) GQA attention of the new tokens against the
     paged cache.  The arithmetic at the reference call site
     (vllm_metax/v1/attention/backends/flash_attn.py:725-747) is inside the closed
@@ -220,11 +220,16 @@ def paged_prefill_attention(query, key_cache, value_cache, num_kv_heads, scale, 
             continue
         ctx = L - ql
         for h in range(H):
-            k, v = _gather_kv(key_cache, value_cache, block_tables[s], L, h // G)
+            if h % G == 0:      # the G query heads of a kv head share one gathered K / V
+                k, v = _gather_kv(key_cache, value_cache, block_tables[s], L, h // G)
             sc = scale * (query[q0:q1, h].float() @ k.float().T)          # [ql, L]
             qi = torch.arange(ql)[:, None]
             ki = torch.arange(L)[None, :]
+            if softcap:                                     # test_flash_attn.py:66-67: before the mask
+                sc = softcap * torch.tanh(sc / softcap)
             sc = sc.masked_fill(ki > (qi + ctx), float("-inf"))
+            if sliding_window:                              # :60-65: keys pos - W + 1 .. pos stay visible
+                sc = sc.masked_fill(ki < (qi + ctx - sliding_window + 1), float("-inf"))
             p = torch.softmax(sc, dim=-1).to(v.dtype)
             out[q0:q1, h] = (p.float() @ v.float()).to(query.dtype)
     return out
@@ -351,6 +356,13 @@ def rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox):
         return xv.reshape(shape)
 
     return apply(query), apply(key)
+
+
+def batched_rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox, cos_sin_cache_offsets):
+    """csrc/pos_encoding_kernels.cu:102-129: cache row = positions + cos_sin_cache_offsets (several LoRA
+    rope tables stacked in one cache).  Cross-check: tests/kernels/core/test_pos_encoding.py:126-192."""
+    return rotary_embedding(positions.reshape(-1) + cos_sin_cache_offsets.reshape(-1), query, key, head_size,
+                            cos_sin_cache, is_neox)
 
 
 # ========================================================================== activation

@@ -84,7 +84,7 @@ def test_torch_bindings_register_reference_op_names(built):
     import vllm_metax_amd._C  # noqa: F401
     for name in ["paged_attention_v1", "paged_attention_v2", "rms_norm", "fused_add_rms_norm",
                  "rms_norm_static_fp8_quant", "fused_add_rms_norm_static_fp8_quant",
-                 "rms_norm_dynamic_per_token_quant", "rotary_embedding", "awq_gemm",
+                 "rms_norm_dynamic_per_token_quant", "rotary_embedding", "batched_rotary_embedding", "awq_gemm",
                  "awq_dequantize", "awq_to_gptq_4bit", "gptq_gemm", "gptq_shuffle",
                  "cutlass_scaled_mm", "cutlass_scaled_mm_supports_fp8", "static_scaled_fp8_quant",
                  "dynamic_scaled_fp8_quant", "dynamic_per_token_scaled_fp8_quant", "silu_and_mul",

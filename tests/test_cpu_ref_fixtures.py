@@ -75,7 +75,7 @@ def test_paged_attention_reference_sharp():
 
 
 # ------------------------------------------------------------------------------ a13
-@pytest.mark.parametrize("name", ["ref_flash_paged_plain"])
+@pytest.mark.parametrize("name", ["ref_flash_paged_plain", "ref_flash_paged_opts"])
 def test_paged_prefill_reference(name):
     """ref_paged_attn (test_flash_attn.py:27-80) on its own (query_len, kv_len) grid: the reference's
     tolerance atol 1.5e-2 / rtol 1e-2 (:183) against its bf16 evaluation; 1e-3 * max|ref| + one bf16
@@ -87,7 +87,7 @@ def test_paged_prefill_reference(name):
         kc, vc = RI.nhd_to_xsplit(kc_nhd, vc_nhd)
         cu = torch.tensor([0] + m["query_lens"], dtype=torch.int32).cumsum(0).to(torch.int32)
         sl = torch.tensor(m["kv_lens"], dtype=torch.int32)
-        o = R.paged_prefill_attention(q, kc, vc, m["KVH"], m["scale"], bt, sl, cu)
+        o = R.paged_prefill_attention(q, kc, vc, m["KVH"], m["scale"], bt, sl, cu, m["window"], m["softcap"])
         if f"c{i}_out" in z:
             torch.testing.assert_close(o.float(), RI.arr(z, i, "out", BF).float(), atol=1.5e-2, rtol=1e-2)
         if f"c{i}_out_f32" in z:

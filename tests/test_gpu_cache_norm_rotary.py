@@ -326,6 +326,36 @@ def test_rotary_embedding_3d_and_batched_positions():
     assert_bit_exact(kd, ref_k, "k")
 
 
+@pytest.mark.parametrize("is_neox", [True, False])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_batched_rotary_embedding(is_neox, dtype):
+    """batched_rotary_embedding (multi-LoRA rope tables stacked in one cache; csrc/pos_encoding_kernels.cu:
+    102-129, :219-306): cache row = position + per-token offset; via the ctypes op and torch.ops._C, both
+    bit-exact against the oracle.  Grid as tests/kernels/core/test_pos_encoding.py:126-192 (scaled down)."""
+    import vllm_metax_amd._C  # noqa: F401
+    torch.manual_seed(1)
+    T, H, KVH, hs, rot, max_pos, tables = 37, 8, 2, 128, 64, 512, 3
+    cache = torch.randn(max_pos * tables, rot).to(dtype)
+    positions = torch.randint(0, max_pos, (T,), dtype=torch.int64)
+    offsets = torch.randint(0, tables, (T,), dtype=torch.int64) * max_pos
+    q = torch.randn(T, H * hs).to(dtype)
+    k = torch.randn(T, KVH * hs).to(dtype)
+    ref_q, ref_k = R.batched_rotary_embedding(positions, q, k, hs, cache, is_neox, offsets)
+    d = dev()
+    for call in ("ctypes", "torch.ops"):
+        qd, kd = q.to(d), k.to(d)
+        if call == "ctypes":
+            ops().batched_rotary_embedding(positions.to(d), qd, kd, hs, cache.to(d), is_neox, rot, offsets.to(d))
+        else:
+            torch.ops._C.batched_rotary_embedding(positions.to(d), qd, kd, hs, cache.to(d), is_neox, rot,
+                                                  offsets.to(d))
+        assert_bit_exact(qd, ref_q, f"q ({call})")
+        assert_bit_exact(kd, ref_k, f"k ({call})")
+    with pytest.raises(RuntimeError):
+        ops().batched_rotary_embedding(positions.to(d), q.to(d), None, hs, cache.to(d), is_neox, rot,
+                                       offsets[:5].to(d))
+
+
 # ------------------------------------------------------------------------- activation
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("d_", [13, 512, 2048, 14336])

@@ -65,8 +65,10 @@ def test_paged_attention_reference_sharp():
             close_to_f32(_decode(m, q, kc, vc, bt, sl, slopes, version), ref32, f"sharp[{i}] v{version}")
 
 
-def test_paged_prefill_reference():
-    z, meta = RI.load("ref_flash_paged_plain")
+@pytest.mark.parametrize("name", ["ref_flash_paged_plain", "ref_flash_paged_opts"])
+def test_paged_prefill_reference(name):
+    """ref_flash_paged_opts: sliding window 256 and / or soft-cap 50 (test_flash_attn.py:23-24 grid)."""
+    z, meta = RI.load(name)
     d = dev()
     for i, m in enumerate(meta):
         q, kc_nhd, vc_nhd, bt = RI.prefill_inputs(m)
@@ -76,7 +78,8 @@ def test_paged_prefill_reference():
         sl = torch.tensor(m["kv_lens"], dtype=torch.int32)
         out = torch.full(q.shape, float("nan"), dtype=BF, device=d)
         ops().paged_prefill_attention(out, q.to(d), kc.to(d), vc.to(d), m["KVH"], m["scale"], bt.to(d), sl.to(d),
-                                      cu.to(d), max(m["query_lens"]), m["bs"])
+                                      cu.to(d), max(m["query_lens"]), m["bs"], "auto", None, None,
+                                      m["window"], m["softcap"])
         torch.cuda.synchronize()
         o = out.cpu()
         if f"c{i}_out" in z:

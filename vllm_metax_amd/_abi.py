@@ -44,7 +44,7 @@ PROTOTYPES = {
              _I, _I, _P, _P, _P]),
     "mi355x_paged_prefill_attention": (
         _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _I, _L, _L, _L, _L, _I, _I, _P,
-             _P, _P]),
+             _P, _I, _F, _P]),
     "mi355x_rms_norm": (_I, [_P, _P, _P, _F, _I, _I, _L, _I, _P]),
     "mi355x_fused_add_rms_norm": (_I, [_P, _P, _P, _F, _I, _I, _L, _I, _P]),
     "mi355x_fused_add_rms_norm_slabs": (_I, [_P, _P, _P, _P, _I, _F, _I, _I, _L, _I, _P]),
@@ -58,6 +58,8 @@ PROTOTYPES = {
     "mi355x_dynamic_per_token_scaled_fp8_quant": (_I, [_P, _P, _P, _P, _I, _I, _L, _L, _I, _P]),
     "mi355x_rotary_embedding": (
         _I, [_P, _P, _P, _P, _I, _I, _L, _L, _L, _I, _I, _I, _I, _I, _P]),
+    "mi355x_batched_rotary_embedding": (
+        _I, [_P, _P, _P, _P, _P, _I, _I, _L, _L, _L, _I, _I, _I, _I, _I, _P]),
     "mi355x_silu_and_mul": (_I, [_P, _P, _I, _I, _I, _P]),
     "mi355x_silu_and_mul_quant": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mi355x_awq_to_gptq_4bit": (_I, [_P, _P, _I, _I, _P]),

@@ -274,7 +274,8 @@ def paged_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: t
                             cu_seqlens_q: torch.Tensor, max_query_len: int,
                             block_size: int, kv_cache_dtype: str = "auto",
                             k_scale: Optional[torch.Tensor] = None,
-                            v_scale: Optional[torch.Tensor] = None) -> None:
+                            v_scale: Optional[torch.Tensor] = None, sliding_window: Optional[int] = None,
+                            softcap: Optional[float] = None) -> None:
     """Varlen causal attention of the new tokens against the paged cache (the role of
     flash_attn_varlen_func(block_table=...) at the reference call site
     vllm_metax/v1/attention/backends/flash_attn.py:725-747)."""
@@ -285,7 +286,8 @@ def paged_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: t
         query.size(1), num_kv_heads, query.size(2), block_size, float(scale),
         _ptr(block_tables), _ptr(seq_lens), _ptr(cu_seqlens_q), max_query_len,
         block_tables.size(1), query.stride(0), out.stride(0), key_cache.stride(0),
-        key_cache.stride(1), _dt(query), kvd, ks, vs, _stream())
+        key_cache.stride(1), _dt(query), kvd, ks, vs, int(sliding_window or 0), float(softcap or 0.0),
+        _stream())
     _abi.check(rc, "paged_prefill_attention")
 
 
@@ -445,11 +447,23 @@ def dynamic_per_token_scaled_fp8_quant(out: torch.Tensor, input: torch.Tensor,
 
 
 # ---------------------------------------------------------------------------- rotary
+def batched_rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: Optional[torch.Tensor],
+                             head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool, rot_dim: int,
+                             cos_sin_cache_offsets: torch.Tensor) -> None:
+    """ref launcher: csrc/pos_encoding_kernels.cu:219-306 (row = position + offset of the token's LoRA)."""
+    if cos_sin_cache_offsets.dtype != torch.int64 or cos_sin_cache_offsets.numel() != positions.numel():
+        raise RuntimeError("positions must have the same num_tokens or batch_size as cos_sin_cache_offsets")
+    if rot_dim != cos_sin_cache.size(1):
+        raise RuntimeError("rot_dim must equal cos_sin_cache.size(1)")
+    rotary_embedding(positions, query, key, head_size, cos_sin_cache, is_neox, cos_sin_cache_offsets)
+
+
 def rotary_embedding(positions: torch.Tensor, query: torch.Tensor,
                      key: Optional[torch.Tensor], head_size: int,
-                     cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+                     cos_sin_cache: torch.Tensor, is_neox: bool,
+                     _offsets: Optional[torch.Tensor] = None) -> None:
     """ref launcher: csrc/pos_encoding_kernels.cu:133-213 (shape / stride handling)."""
-    _dev(positions, query, key, cos_sin_cache)
+    _dev(positions, query, key, cos_sin_cache, _offsets)
     if positions.dtype != torch.int64:
         raise RuntimeError("positions must be int64")
     num_tokens = positions.numel()
@@ -478,6 +492,13 @@ def rotary_embedding(positions: torch.Tensor, query: torch.Tensor,
     key_stride = key.stride(seq_dim_idx) if key is not None else 0
     query_ndim = query.dim()
     head_stride = query.stride(-2) if query_ndim == pdim + 2 else head_size
+    if _offsets is not None:
+        rc = _abi.load().mi355x_batched_rotary_embedding(
+            _ptr(positions), _ptr(query), _ptr(key), _ptr(cos_sin_cache), _ptr(_offsets), num_tokens,
+            rot_dim, query_stride, key_stride, head_stride, num_heads, num_kv_heads, head_size,
+            1 if is_neox else 0, _dt(query), _stream())
+        _abi.check(rc, "batched_rotary_embedding")
+        return
     rc = _abi.load().mi355x_rotary_embedding(
         _ptr(positions), _ptr(query), _ptr(key), _ptr(cos_sin_cache), num_tokens, rot_dim,
         query_stride, key_stride, head_stride, num_heads, num_kv_heads, head_size,

@@ -211,7 +211,8 @@ def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
                             md: Mi355xPagedMetadata, output: torch.Tensor, num_kv_heads: int,
                             scale: float, alibi_slopes: Optional[torch.Tensor] = None,
                             kv_cache_dtype: str = "auto", k_scale: Optional[torch.Tensor] = None,
-                            v_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            v_scale: Optional[torch.Tensor] = None, sliding_window: Optional[int] = None,
+                            softcap: Optional[float] = None) -> torch.Tensor:
     """query [T, H, d], key/value [T, KVH, d] (may be padded past num_actual_tokens),
     output [T, H, d] caller-provided (accept_output_buffer, flash_attn.py:56)."""
     head_size = query.shape[-1]
@@ -223,6 +224,10 @@ def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
         ops.reshape_and_cache(key, value, key_cache, value_cache, md.slot_mapping[:n], kv_cache_dtype,
                               k_scale, v_scale)
     nd, ndt = md.num_decodes, md.num_decode_tokens
+    if nd > 0 and (sliding_window or softcap):
+        # paged_attention_v1/v2 have no such arguments in the reference either (schema
+        # csrc/torch_bindings.cpp:45-69); the prefill kernel takes them (flash_attn.py:725-747)
+        raise RuntimeError("sliding window / soft-cap are supported on the prefill path only")
     if nd > 0:
         decode_attention(output[:ndt], md.exp_sums, md.max_logits, md.tmp_out, query[:ndt],
                          key_cache, value_cache, num_kv_heads, scale, md.block_table[:nd],
@@ -234,7 +239,7 @@ def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
         ops.paged_prefill_attention(output[ndt:n], query[ndt:n], key_cache, value_cache,
                                     num_kv_heads, scale, md.block_table[nd:], md.seq_lens[nd:],
                                     md.prefill_query_start_loc, md.max_prefill_query_len, block_size,
-                                    kv_cache_dtype, k_scale, v_scale)
+                                    kv_cache_dtype, k_scale, v_scale, sliding_window, softcap)
     return output
 
 

@@ -363,7 +363,8 @@ __global__ __launch_bounds__(64) void paged_prefill_generic_kernel(
     int block_size, float scale, const int* __restrict__ block_tables,
     const int* __restrict__ seq_lens, const int* __restrict__ cu_seqlens_q, int num_seqs,
     int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
-    int64_t kv_head_stride, const float* __restrict__ k_scale, const float* __restrict__ v_scale) {
+    int64_t kv_head_stride, const float* __restrict__ k_scale, const float* __restrict__ v_scale,
+    int window, float softcap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* qs = reinterpret_cast<float*>(smem);  // [head_size]
   const int tok = blockIdx.x;
@@ -397,19 +398,26 @@ __global__ __launch_bounds__(64) void paged_prefill_generic_kernel(
     for (int d = 0; d < head_size; ++d) {
       acc += qs[d] * cache_to_f32<CT>(kp[((d / X) * block_size + off) * X + (d % X)]);
     }
-    return acc * scale;
+    acc *= scale;
+    // logit soft-capping (the call site's `softcap`, flash_attn.py:725-747): cap * tanh(s / cap), on
+    // the scaled score, before masking — as the reference's test oracle test_flash_attn.py:66-67
+    if (softcap > 0.f) acc = softcap * tanhf(acc / softcap);
+    return acc;
   };
+  // sliding window (`window_size = (W - 1, 0)` at the call site): a query at absolute position p sees
+  // keys p - W + 1 .. p (test_flash_attn.py:60-65)
+  const int first = window > 0 ? max(visible - window, 0) : 0;
   float m = kNegBig;
-  for (int key = lane; key < visible; key += 64) m = fmaxf(m, kdot(key));
+  for (int key = first + lane; key < visible; key += 64) m = fmaxf(m, kdot(key));
   m = wave_max(m);
   float lsum = 0.f;
-  for (int key = lane; key < visible; key += 64) lsum += __expf(kdot(key) - m);
+  for (int key = first + lane; key < visible; key += 64) lsum += __expf(kdot(key) - m);
   lsum = wave_sum(lsum);
   const float inv = 1.0f / lsum;
   // PV: lanes over d, serial over keys (probabilities recomputed; rounded to T like the oracle)
   for (int d = lane; d < head_size; d += 64) {
     float acc = 0.f;
-    for (int key = 0; key < visible; ++key) {
+    for (int key = first; key < visible; ++key) {
       const int64_t pb = block_table[key / block_size];
       const int off = key % block_size;
       const CT* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
@@ -430,7 +438,9 @@ extern "C" int mi355x_paged_prefill_attention(
     const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
     int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
     int64_t kv_head_stride, int dtype, int kv_cache_dtype, const float* k_scale,
-    const float* v_scale, mi355x_stream stream) {
+    const float* v_scale, int sliding_window, float softcap, mi355x_stream stream) {
+  MI355X_REQUIRE(sliding_window >= 0 && softcap >= 0.f, MI355X_EINVAL,
+                 "paged_prefill_attention: sliding_window / softcap must be >= 0 (0 = off)");
   MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3,
                  MI355X_EUNSUPPORTED, "Unsupported data type of kv cache: id %d", kv_cache_dtype);
   const bool kv8 = kv_cache_dtype == MI355X_KV_FP8_E4M3;
@@ -448,7 +458,9 @@ extern "C" int mi355x_paged_prefill_attention(
                      cu_seqlens_q,
                  MI355X_EINVAL, "paged_prefill_attention: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool fast = head_size == 128 && block_size == 16 && dtype != MI355X_F32 &&
+  // sliding window / soft-cap: the general kernel only (correctness path; no BASELINE config uses them)
+  const bool fast = sliding_window == 0 && softcap == 0.f &&
+                    head_size == 128 && block_size == 16 && dtype != MI355X_F32 &&
                     q_stride % 8 == 0 && out_stride % 4 == 0 &&
                     ((reinterpret_cast<uintptr_t>(query) | reinterpret_cast<uintptr_t>(key_cache) |
                       reinterpret_cast<uintptr_t>(value_cache)) & 15) == 0 &&
@@ -487,7 +499,7 @@ extern "C" int mi355x_paged_prefill_attention(
                          static_cast<const uint8_t*>(value_cache), num_heads, num_kv_heads, head_size,
                          block_size, scale, block_tables, seq_lens, cu_seqlens_q, num_seqs,
                          max_num_blocks_per_seq, q_stride, out_stride, kv_block_stride,
-                         kv_head_stride, k_scale, v_scale);
+                         kv_head_stride, k_scale, v_scale, sliding_window, softcap);
     } else {
       hipLaunchKernelGGL((paged_prefill_generic_kernel<scalar_t, scalar_t>), grid, block,
                          (size_t)head_size * sizeof(float), s, static_cast<scalar_t*>(out),
@@ -495,7 +507,7 @@ extern "C" int mi355x_paged_prefill_attention(
                          static_cast<const scalar_t*>(value_cache), num_heads, num_kv_heads, head_size,
                          block_size, scale, block_tables, seq_lens, cu_seqlens_q, num_seqs,
                          max_num_blocks_per_seq, q_stride, out_stride, kv_block_stride,
-                         kv_head_stride, k_scale, v_scale);
+                         kv_head_stride, k_scale, v_scale, sliding_window, softcap);
     }
     return check_launch("paged_prefill_attention(generic)");
   });

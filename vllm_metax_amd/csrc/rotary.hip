@@ -16,9 +16,12 @@ __global__ void rotary_embedding_kernel(const int64_t* __restrict__ positions,
                                         const T* __restrict__ cos_sin_cache, int rot_dim,
                                         int64_t query_stride, int64_t key_stride,
                                         int64_t head_stride, int num_heads,
-                                        int num_kv_heads) {
+                                        int num_kv_heads,
+                                        const int64_t* __restrict__ cache_offsets) {
   const int64_t token = blockIdx.x;
-  const int64_t pos = positions[token];
+  // batched_rotary_embedding (multi-LoRA): the cache row is offsets[token] + position
+  // (csrc/pos_encoding_kernels.cu:102-129)
+  const int64_t pos = positions[token] + (cache_offsets ? cache_offsets[token] : 0);
   const int embed_dim = rot_dim / 2;
   const T* cos_ptr = cos_sin_cache + pos * rot_dim;
   const T* sin_ptr = cos_ptr + embed_dim;
@@ -84,14 +87,12 @@ using namespace mi355x;
 #define LAUNCH_ROT(NEOX, VECF)                                                            \
   hipLaunchKernelGGL((rotary_embedding_kernel<scalar_t, NEOX, VECF>), grid, block, 0, s,   \
                      positions, q, k, cache, rot_dim, query_stride, key_stride, head_stride, \
-                     num_heads, num_kv_heads)
+                     num_heads, num_kv_heads, cache_offsets)
 
-extern "C" int mi355x_rotary_embedding(const int64_t* positions, void* query, void* key,
-                                       const void* cos_sin_cache, int num_tokens,
-                                       int rot_dim, int64_t query_stride,
-                                       int64_t key_stride, int64_t head_stride,
-                                       int num_heads, int num_kv_heads, int head_size,
-                                       int is_neox, int dtype, mi355x_stream stream) {
+static int rotary_impl(const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
+                       int num_tokens, int rot_dim, int64_t query_stride, int64_t key_stride,
+                       int64_t head_stride, int num_heads, int num_kv_heads, int head_size,
+                       int is_neox, int dtype, const int64_t* cache_offsets, mi355x_stream stream) {
   MI355X_REQUIRE(num_tokens >= 0 && rot_dim > 0 && rot_dim % 2 == 0 && num_heads > 0 &&
                      num_kv_heads >= 0 && head_size > 0,
                  MI355X_EINVAL, "rotary_embedding: bad sizes");
@@ -123,4 +124,29 @@ extern "C" int mi355x_rotary_embedding(const int64_t* positions, void* query, vo
     }
     return check_launch("rotary_embedding");
   });
+}
+
+extern "C" int mi355x_rotary_embedding(const int64_t* positions, void* query, void* key,
+                                       const void* cos_sin_cache, int num_tokens,
+                                       int rot_dim, int64_t query_stride,
+                                       int64_t key_stride, int64_t head_stride,
+                                       int num_heads, int num_kv_heads, int head_size,
+                                       int is_neox, int dtype, mi355x_stream stream) {
+  return rotary_impl(positions, query, key, cos_sin_cache, num_tokens, rot_dim, query_stride,
+                     key_stride, head_stride, num_heads, num_kv_heads, head_size, is_neox, dtype,
+                     nullptr, stream);
+}
+
+extern "C" int mi355x_batched_rotary_embedding(const int64_t* positions, void* query, void* key,
+                                               const void* cos_sin_cache,
+                                               const int64_t* cos_sin_cache_offsets, int num_tokens,
+                                               int rot_dim, int64_t query_stride, int64_t key_stride,
+                                               int64_t head_stride, int num_heads, int num_kv_heads,
+                                               int head_size, int is_neox, int dtype,
+                                               mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens == 0 || cos_sin_cache_offsets, MI355X_EINVAL,
+                 "batched_rotary_embedding: cos_sin_cache_offsets is null");
+  return rotary_impl(positions, query, key, cos_sin_cache, num_tokens, rot_dim, query_stride,
+                     key_stride, head_stride, num_heads, num_kv_heads, head_size, is_neox, dtype,
+                     cos_sin_cache_offsets, stream);
 }

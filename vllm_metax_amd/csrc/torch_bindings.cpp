@@ -231,9 +231,10 @@ void rms_norm_dynamic_per_token_quant(Tensor& out, const Tensor& input, const Te
 }
 
 // ---------------------------------------------------------------------- rotary
-void rotary_embedding(Tensor& positions, Tensor& query, std::optional<Tensor> key,
-                      int64_t head_size, Tensor& cos_sin_cache, bool is_neox) {
-  // shape / stride handling as in the reference launcher (pos_encoding_kernels.cu:133-213)
+static void rotary_common(Tensor& positions, Tensor& query, std::optional<Tensor>& key,
+                          int64_t head_size, Tensor& cos_sin_cache, bool is_neox,
+                          const int64_t* offsets) {
+  // shape / stride handling as in the reference launchers (pos_encoding_kernels.cu:133-213, :219-306)
   const int64_t num_tokens = positions.numel();
   const int pdim = positions.dim();
   TORCH_CHECK(pdim == 1 || pdim == 2,
@@ -258,12 +259,40 @@ void rotary_embedding(Tensor& positions, Tensor& query, std::optional<Tensor> ke
   const int64_t key_stride = has_key ? key->stride(seq_dim) : 0;
   const int64_t head_stride = (query.dim() == pdim + 2) ? query.stride(-2) : head_size;
   Guard g(query);
+  if (offsets) {
+    ok(mi355x_batched_rotary_embedding(positions.data_ptr<int64_t>(), query.data_ptr(),
+                                       has_key ? key->data_ptr() : nullptr, cos_sin_cache.data_ptr(),
+                                       offsets, num_tokens, cos_sin_cache.size(1), query_stride,
+                                       key_stride, head_stride, num_heads, num_kv_heads, head_size,
+                                       is_neox ? 1 : 0, dt(query), stream_of(query)),
+       "batched_rotary_embedding");
+    return;
+  }
   ok(mi355x_rotary_embedding(positions.data_ptr<int64_t>(), query.data_ptr(),
                              has_key ? key->data_ptr() : nullptr, cos_sin_cache.data_ptr(),
                              num_tokens, cos_sin_cache.size(1), query_stride, key_stride,
                              head_stride, num_heads, num_kv_heads, head_size, is_neox ? 1 : 0,
                              dt(query), stream_of(query)),
      "rotary_embedding");
+}
+
+void rotary_embedding(Tensor& positions, Tensor& query, std::optional<Tensor> key,
+                      int64_t head_size, Tensor& cos_sin_cache, bool is_neox) {
+  rotary_common(positions, query, key, head_size, cos_sin_cache, is_neox, nullptr);
+}
+
+// ref: csrc/pos_encoding_kernels.cu:219-306
+void batched_rotary_embedding(Tensor& positions, Tensor& query, std::optional<Tensor> key,
+                              int64_t head_size, Tensor& cos_sin_cache, bool is_neox, int64_t rot_dim,
+                              Tensor& cos_sin_cache_offsets) {
+  TORCH_CHECK(positions.size(0) == cos_sin_cache_offsets.size(0) ||
+                  positions.numel() == cos_sin_cache_offsets.size(0),
+              "positions must have the same num_tokens or batch_size as cos_sin_cache_offsets");
+  TORCH_CHECK(rot_dim == cos_sin_cache.size(1), "rot_dim must equal cos_sin_cache.size(1)");
+  TORCH_CHECK(cos_sin_cache_offsets.numel() == positions.numel(),
+              "one cache offset per token is expected");
+  rotary_common(positions, query, key, head_size, cos_sin_cache, is_neox,
+                cos_sin_cache_offsets.data_ptr<int64_t>());
 }
 
 // ------------------------------------------------------------- int4 weight-only
@@ -656,6 +685,14 @@ TORCH_LIBRARY(_C, ops) {
       "                 Tensor!? key, int head_size,"
       "                 Tensor cos_sin_cache, bool is_neox) -> ()");
   ops.impl("rotary_embedding", c10::kCUDA, &rotary_embedding);
+
+  ops.def(
+      "batched_rotary_embedding(Tensor positions, Tensor! query,"
+      "                         Tensor!? key, int head_size,"
+      "                         Tensor cos_sin_cache, bool is_neox,"
+      "                         int rot_dim,"
+      "                         Tensor cos_sin_cache_offsets) -> ()");
+  ops.impl("batched_rotary_embedding", c10::kCUDA, &batched_rotary_embedding);
 
   ops.def(
       "awq_gemm(Tensor _in_feats, Tensor _kernel, Tensor _scaling_factors, "
