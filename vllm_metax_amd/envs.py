@@ -8,6 +8,8 @@ environment_variables: dict[str, Callable[[], Any]] = {
     "MI355X_PA_ALLOW_V1": lambda: os.getenv("MI355X_PA_ALLOW_V1", "0") == "1",
     # maximum tokens per prefill chunk the backend assumes when sizing workspaces
     "MI355X_MAX_BATCHED_TOKENS": lambda: int(os.getenv("MI355X_MAX_BATCHED_TOKENS", "8192")),
+    # keep a dequantised operand image of every int4 layer for the prefill GEMM (n*k*2 bytes per layer)
+    "MI355X_PREPACK_WEIGHTS": lambda: os.getenv("MI355X_PREPACK_WEIGHTS", "0") == "1",
     # fraction of the 288 GB HBM3E the KV pool may take (config sizing helper)
     "MI355X_KV_FRACTION": lambda: float(os.getenv("MI355X_KV_FRACTION", "0.9")),
 }

@@ -34,6 +34,8 @@ class AWQLinearMethod(_AWQLinearMethod):
         layer.qweight = torch.nn.Parameter(
             linear.awq_process_weights(layer.qweight.data, self.quant_config.group_size),
             requires_grad=False)
+        if self.quant_config.group_size % 32 == 0:
+            linear.register_prefill_image(layer.qweight.data, layer.qzeros.data, layer.scales.data, False)
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor,
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -32,6 +32,8 @@ class GPTQLinearMethod(_GPTQLinearMethod):
                                             self.quant_config.weight_bits)
         layer.g_idx = torch.nn.Parameter(g_idx, requires_grad=False)
         layer.exllama_state = ExllamaState.READY
+        if self.quant_config.weight_bits == 4 and not self.quant_config.desc_act:
+            linear.register_prefill_image(layer.qweight.data, layer.qzeros.data, layer.scales.data, True)
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor,
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:

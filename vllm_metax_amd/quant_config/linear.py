@@ -10,6 +10,28 @@ from typing import Optional
 import torch
 
 from .. import _custom_ops as ops
+from .. import envs
+
+# Optional (MI355X_PREPACK_WEIGHTS=1): the prefill GEMM's weight operand image, dequantised once in
+# process_weights_after_loading instead of inside every prefill-sized awq_gemm / gptq_gemm call
+# (n * k * 2 bytes per layer; bit-identical results).  Keyed by the repacked qweight's address so that the
+# reference's _apply_awq / _apply_gptq op signatures stay as they are.
+_PREPACKED: dict = {}
+
+
+def register_prefill_image(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                           gptq_zeros: bool) -> None:
+    if not envs.MI355X_PREPACK_WEIGHTS or scales.dtype == torch.float32:
+        return
+    n = scales.shape[1]
+    k = qweight.numel() * 8 // n
+    if n % 64 or k % 32 or (k // scales.shape[0]) % 32:
+        return
+    _PREPACKED[qweight.data_ptr()] = (ops.w4a16_prepack(qweight, qzeros, scales, gptq_zeros), n, k)
+
+
+def _prefill_image(qweight: torch.Tensor, m: int):
+    return _PREPACKED.get(qweight.data_ptr()) if m >= 1024 else None
 
 
 def awq_process_weights(qweight: torch.Tensor, group_size: int) -> torch.Tensor:
@@ -34,8 +56,12 @@ def apply_awq(x: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzer
         temp_space = torch.empty(0, dtype=torch.float32, device=x.device)
         if reshaped_x.shape[0] <= 64:             # split-K workspace only matters for decode
             temp_space = torch.zeros(reshaped_x.shape[0], n, dtype=torch.float32, device=x.device)
-        out = ops.awq_gemm(reshaped_x, qweight, qzeros, scales, pack_factor, temp_space,
-                           reshaped_x.dtype == torch.bfloat16)
+        img = _prefill_image(qweight, reshaped_x.shape[0])
+        if img is not None and reshaped_x.stride(-1) == 1:
+            out = ops.w4a16_gemm_prepacked(reshaped_x, img[0], img[1], img[2])
+        else:
+            out = ops.awq_gemm(reshaped_x, qweight, qzeros, scales, pack_factor, temp_space,
+                               reshaped_x.dtype == torch.bfloat16)
     if bias is not None:
         out.add_(bias)
     return out.reshape(out_shape)
@@ -73,8 +99,12 @@ def apply_gptq(x: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qze
     if reshaped_x.shape[0] <= 64:
         temp_space = torch.zeros(reshaped_x.shape[0], qweight.shape[1], dtype=torch.float32,
                                  device=x.device)
-    out = ops.gptq_gemm(reshaped_x, qweight, qzeros, scales, g_idx, use_exllama, weight_bits,
-                        group_size, perm_space, temp_space, reshaped_x.dtype == torch.bfloat16)
+    img = _prefill_image(qweight, reshaped_x.shape[0]) if (weight_bits == 4 and not desc_act) else None
+    if img is not None and reshaped_x.is_contiguous():
+        out = ops.w4a16_gemm_prepacked(reshaped_x, img[0], img[1], img[2])
+    else:
+        out = ops.gptq_gemm(reshaped_x, qweight, qzeros, scales, g_idx, use_exllama, weight_bits,
+                            group_size, perm_space, temp_space, reshaped_x.dtype == torch.bfloat16)
     if bias is not None:
         out.add_(bias)
     return out.reshape(out_shape)
