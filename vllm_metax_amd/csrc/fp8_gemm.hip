@@ -424,31 +424,66 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
   }
   const int frag = frag_swz(lr, lc);
   int cur = 0;
-  for (int ks = 0; ks < kstages; ++ks) {
-    if (ks + S - 2 < kstages) lds_dma_wait<4 * P * (S - 2)>();
+  if constexpr (P == 1) {
+    // ping-pong of the two waves of a SIMD, as in gemm_packed_kernel (w4a16_unfused.hip): waves 4-7 enter
+    // the loop one barrier late; an iteration is {12 fragment reads of stage ks, copies of stage ks+S-1,
+    // own copies of stage ks+1 retired} barrier {32 MFMAs} barrier.
+    if (kstages >= S - 1) lds_dma_wait<4 * (S - 2)>();
     else lds_dma_wait<0>();
     __syncthreads();
-    {
-      const int nxt = ks + S - 1;
-      int slot = cur + S - 1;
-      slot = slot >= S ? slot - S : slot;
-      if (nxt < kstages) stage(slot, nxt);
-    }
-    const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
-    const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
-    if constexpr (P == 1) {
+    if (wave >= 4) __builtin_amdgcn_s_barrier();
+    for (int ks = 0; ks < kstages; ++ks) {
+      const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
+      const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
       uint4 bf[4], af[8];
 #pragma unroll
       for (int t = 0; t < 4; ++t) bf[t] = bbuf[t * 64];
 #pragma unroll
       for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
       __builtin_amdgcn_sched_barrier(0);
+      const int nxt = ks + S - 1;
+      int slot = cur + S - 1;
+      slot = slot >= S ? slot - S : slot;
+      if (nxt < kstages) {
+        stage(slot, nxt);
+        lds_dma_wait<4 * (S - 2)>();
+      } else {
+        lds_dma_wait<0>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[i][t] = Op::run16(af[i], bf[t], acc[i][t]);
       }
-    } else {
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur + 1 == S ? 0 : cur + 1;
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();
+  } else {
+    // two 64-KiB stages, all 8 waves in phase, one barrier per stage.  (The ping-pong needs a copy's
+    // issue -> retire window to span a barrier epoch pair; with only two slots both groups' copies of stage
+    // ks+1 would have to go out and retire within epochs 2ks .. 2ks+1 — built and measured 4 % SLOWER than
+    // this loop, 1803 vs 1727 us per Llama-3-8B layer at M = 8192.)
+    for (int ks = 0; ks < kstages; ++ks) {
+      if (ks + S - 2 < kstages) lds_dma_wait<4 * P * (S - 2)>();
+      else lds_dma_wait<0>();
+      __syncthreads();
+      {
+        const int nxt = ks + S - 1;
+        int slot = cur + S - 1;
+        slot = slot >= S ? slot - S : slot;
+        if (nxt < kstages) stage(slot, nxt);
+      }
+      const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
+      const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
       uint4 bf[4][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -472,8 +507,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
           }
         }
       }
+      cur = cur + 1 == S ? 0 : cur + 1;
     }
-    cur = cur + 1 == S ? 0 : cur + 1;
   }
   if constexpr (IL) {
     const int col = nb * 256 + wn * 64 + 4 * lc;

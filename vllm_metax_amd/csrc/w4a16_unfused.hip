@@ -100,12 +100,31 @@ __global__ __launch_bounds__(256) void w8_dequant_pack_kernel(
 // transfer is a lane-linear 1 KiB LDS-DMA copy (no VGPR staging, no address shuffles), the
 // inner loop is ds_read_b128 + MFMA only.  256 x 256 tile, 8 waves (2 x 4), each wave 128 x 64.
 // K advances in stages of 32 (32 KiB of LDS: 16 A pieces + 16 B pieces); kUfStages stages form
-// a ring, the copies of stage t + kUfStages - 1 are issued before the MFMAs of stage t, so up
-// to three stages (96 KiB per CU) are in flight behind the matrix pipe.  One barrier per stage.
+// a ring, the copies of stage t + kUfStages - 1 are issued while stage t is consumed, so up to
+// three stages (96 KiB per CU) are in flight behind the matrix pipe.  The two waves of a SIMD run
+// the loop half an iteration apart (ping-pong, see the loop): one is in its MFMA cluster while the
+// other issues its copies and fragment reads.  M = 8192, kernel alone (scripts/bench_gemm_pp.py):
+// 1358 -> 1493 TFLOP/s on random operands, 1626 -> 2000 on all-zero ones (what is left on random
+// data is the board's clock under toggling operands, not the schedule).
 constexpr int kUfBM = 256;
 constexpr int kUfBN = 256;
 constexpr int kUfBK = 32;
-constexpr int kUfStages = 4;
+#ifndef UF_STAGES
+#define UF_STAGES 4
+#endif
+#ifndef UF_PP_ORDER
+#define UF_PP_ORDER 1   // 0: copies, then fragment reads; 1: reads, then copies; 2: copies inside the MFMA cluster
+#endif
+#ifndef UF_PP_LGKM_AFTER
+#define UF_PP_LGKM_AFTER 0
+#endif
+constexpr int kUfStages = UF_STAGES;
+#ifdef UF_DIST
+constexpr int kUfDist = UF_DIST;             // stages between a copy's issue and its first read
+#else
+constexpr int kUfDist = kUfStages - 1;
+#endif
+static_assert(kUfDist <= kUfStages - 1 - UF_PP_LGKM_AFTER, "a ring slot is re-staged only after its reads retired");
 constexpr int kUfThreads = 512;
 
 // SILU = true: the GEMM is a gate_up projection (n = 2 * ffn, gate columns first) and the epilogue
@@ -188,6 +207,12 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     }
   };
   constexpr int kPerStage = 4;  // copies one wave issues per stage
+  auto stage_one = [&](int buf, int kt, int c) {   // copy c (0..3) of stage()
+    const int i = c >> 1;
+    const int p = wave * 2 + i;
+    if (c & 1) lds_dma16(b_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + kBOff + p * 64) * 16);
+    else lds_dma16(a_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + p * 64) * 16);
+  };
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -197,12 +222,93 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   }
 
 #pragma unroll
-  for (int s = 0; s < kUfStages - 1; ++s) {
+  for (int s = 0; s < kUfDist; ++s) {
+#if !defined(UF_NO_PINGPONG) && UF_PP_ORDER == 2
+    stage(s, s < ktiles ? s : ktiles - 1);   // constant copy count per stage: constant wait counts
+#else
     if (s < ktiles) stage(s, s);
+#endif
   }
 
   const int frag = frag_swz(lr, lc);  // this lane's slot inside a piece
   int cur = 0;                        // ring slot of stage kt
+#ifndef UF_NO_PINGPONG   // (-DUF_NO_PINGPONG: the round-1 loop, all 8 waves in phase, one barrier per stage)
+  // Two wave groups (waves 0-3 / 4-7: one of each per SIMD) run the same loop half an iteration
+  // apart: an iteration is {memory cluster: copies of stage kt+S-1, the 12 fragment reads of stage
+  // kt} barrier {32 MFMAs} barrier, and group 1 enters the loop one barrier late, so that while one
+  // wave of a SIMD is in its MFMA cluster its partner is in its memory cluster.  Barrier epochs:
+  // group 0 reads stage k in epoch 2k, group 1 in epoch 2k+1.
+  //  * RAW: a wave retires its own copies of stage k+1 (counted vmcnt) at the end of its memory
+  //    cluster of stage k (epochs 2k / 2k+1); the first read of stage k+1 is in epoch 2k+2.
+  //  * WAR: slot (k-1) % S is re-staged in the memory cluster of stage k (epoch >= 2k); its last
+  //    reads (group 1, epoch 2k-1) were retired by the lgkmcnt(0) in front of that epoch's barrier.
+#if UF_PP_ORDER == 2
+  lds_dma_wait<kPerStage * (kUfDist - 1)>();                            // own copies of stage 0
+#else
+  if (ktiles >= kUfDist) lds_dma_wait<kPerStage * (kUfDist - 1)>();   // own copies of stage 0
+  else lds_dma_wait<0>();
+#endif
+  __syncthreads();
+  if (wave >= 4) __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    const int nxt = kt + kUfDist;
+    int slot = cur + kUfDist;
+    slot = slot >= kUfStages ? slot - kUfStages : slot;
+#if UF_PP_ORDER == 0
+    if (nxt < ktiles) stage(slot, nxt);
+#endif
+    const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
+    const uint4* bbuf = lds + cur * kStage + kBOff + (SILU ? wn * 2 : wn * 4) * 64 + frag;
+    uint4 bf[4], af[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bf[t] = bbuf[(SILU ? (t < 2 ? t : 6 + t) : t) * 64];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
+#if UF_PP_ORDER == 1
+    __builtin_amdgcn_sched_barrier(0);
+    if (nxt < ktiles) stage(slot, nxt);
+#endif
+#if UF_PP_ORDER == 2
+    lds_dma_wait<kPerStage * (kUfDist - 2)>();   // own copies of stage kt+1 (stage kt+D goes out below)
+#else
+    if (nxt < ktiles) lds_dma_wait<kPerStage * (kUfDist - 1)>();   // own copies of stage kt+1
+    else lds_dma_wait<0>();
+#endif
+#if !UF_PP_LGKM_AFTER
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+#if UF_PP_LGKM_AFTER
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[i][t] = Mfma<T>::run(af[i], bf[t], acc[i][t]);
+#if UF_PP_ORDER == 2
+      // the copies of stage kt + D ride in the MFMA cluster, one every 8 MFMAs (an MFMA holds the
+      // SIMD's vector issue for half of its 16 cycles; the partner's memory cluster is then reads only)
+      if (!(i & 1)) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_one(slot, nxt < ktiles ? nxt : ktiles - 1, i >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur = cur + 1 == kUfStages ? 0 : cur + 1;
+  }
+#if UF_PP_ORDER == 2
+  lds_dma_wait<0>();   // (the clamped copies of the last iterations still target the ring)
+#endif
+  if (wave < 4) __builtin_amdgcn_s_barrier();
+#else
   for (int kt = 0; kt < ktiles; ++kt) {
     // stage kt has landed once at most the copies of the stages issued after it are pending
     if (kt + kUfStages - 2 < ktiles) lds_dma_wait<kPerStage * (kUfStages - 2)>();
@@ -234,6 +340,8 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
 #endif
     cur = cur + 1 == kUfStages ? 0 : cur + 1;
   }
+
+#endif
 
   // ---- epilogue: lane holds 4 consecutive columns per (i, j) --------------------------------
   if constexpr (MODE == 2) {
