@@ -32,6 +32,18 @@ __global__ void k(uint64_t* out, uint32_t seed, int iters) {
                        asm volatile("v_lshrrev_b32 %0, 4, %1" : "=v"(b) : "v"(c));
                        asm volatile("v_and_b32 %0, %1, %2" : "=v"(c) : "v"(d), "v"(a));
                        asm volatile("v_bfe_u32 %0, %1, 4, 4" : "=v"(d) : "v"(a));) }
+    if (WHICH == 5) { REP16(asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(a) : "v"(b), "v"(c), "s"(seed));
+                       asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(b) : "v"(c), "v"(d), "s"(seed));
+                       asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(c) : "v"(d), "v"(a), "s"(seed));
+                       asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(seed));) }
+    if (WHICH == 6) { REP16(asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(a) : "v"(b), "s"(seed), "v"(c));
+                       asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(b) : "v"(c), "v"(d));
+                       asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(c) : "v"(d), "s"(seed), "v"(a));
+                       asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(d) : "v"(a), "v"(b));) }
+    if (WHICH == 7) { REP16(asm volatile("v_cvt_f32_ubyte0_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(f0) : "v"(a));
+                       asm volatile("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(f1) : "v"(b));
+                       asm volatile("v_cvt_f32_u32_e32 %0, %1" : "=v"(f2) : "v"(c));
+                       asm volatile("v_cvt_f32_i32_e32 %0, %1" : "=v"(f3) : "v"(d));) }
   }
   uint64_t t1 = __builtin_readcyclecounter();
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
@@ -39,17 +51,17 @@ __global__ void k(uint64_t* out, uint32_t seed, int iters) {
 }
 int main() {
   uint64_t* d; hipMalloc(&d, 16);
-  const char* names[] = {"v_cvt_f32_ubyteN", "v_cvt_pk_bf16_f32", "v_pk_fma_f32", "v_fma_f32", "and/shift/bfe"};
+  const char* names[] = {"v_cvt_f32_ubyteN", "v_cvt_pk_bf16_f32", "v_pk_fma_f32", "v_fma_f32", "and/shift/bfe", "v_perm_b32", "v_and_or / v_lshl_or", "v_cvt_f32_u32 (sdwa/plain)"};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int waves = 1; waves <= 4; waves *= 2) {
-    for (int w = 0; w < 5; ++w) {
+    for (int w = 0; w < 8; ++w) {
       const int iters = 20000;
       dim3 block(256 * waves), grid(256);  // one block per CU, `waves` waves per SIMD
       #define L(W) hipLaunchKernelGGL(k<W>, grid, block, 0, 0, d, 1u, iters)
       float ms = 0;
       for (int r = 0; r < 2; ++r) {
         hipEventRecord(e0);
-        if (w == 0) L(0); if (w == 1) L(1); if (w == 2) L(2); if (w == 3) L(3); if (w == 4) L(4);
+        if (w == 0) L(0); if (w == 1) L(1); if (w == 2) L(2); if (w == 3) L(3); if (w == 4) L(4); if (w == 5) L(5); if (w == 6) L(6); if (w == 7) L(7);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
       }
       // SIMD-cycles per wave-instruction at 2.4 GHz: time * 2.4e9 / (instructions per SIMD)

@@ -33,41 +33,51 @@
 
 namespace mi355x {
 
-constexpr int kStThreads = 512;
-constexpr int kStBK = 128;
+#ifndef STRIPE_T256
+#define STRIPE_T256 1.25   // cost-model time of a 256-k stage (16 waves) relative to a 128-k stage (8 waves)
+#endif
 
-template <int MT, int NW, int SETS>
+// WV = waves per workgroup: 8 (stages of 128 k) or 16 (stages of 256 k, 4 waves per SIMD).  A wave's own
+// instruction stream — ~120 VALU at one issue per 6-8 cycles, ~100 SALU, the LDS and copy-issue latencies —
+// takes ~2000 cycles per stage whatever its SIMD partner does, so two waves per SIMD leave the vector issue
+// port ~40 % idle; four fill it (profiles/r02_decode_gemm_notes.md).
+template <int MT, int NW, int SETS, int WV>
 struct StripeCfg {
+  static constexpr int THREADS = 64 * WV;
+  static constexpr int BK = 16 * WV;             // k per stage
+  static constexpr int KSTEPS = BK / 32;
+  static constexpr int LOADERS = WV / 2;         // waves [0, LOADERS) feed the weight ring, the rest the activation ring
   static constexpr int BN = 64 * NW;
-  static constexpr int KW = 8 / NW;              // waves along K
-  static constexpr int KS_PER_WAVE = 4 / KW;     // k-steps (of 32) of one stage per wave
+  static constexpr int KW = WV / NW;             // waves along K
+  static constexpr int KS_PER_WAVE = KSTEPS / KW;   // k-steps (of 32) of one stage per wave
   static constexpr int W_ROW_BYTES = BN * 4;     // one packed row = 8 k of every column
-  static constexpr int W_BYTES = 16 * W_ROW_BYTES;
+  static constexpr int W_BYTES = (BK / 8) * W_ROW_BYTES;
   static constexpr int SC_LANES = 8 * NW;        // 16-B pieces of the BN scales (2 B each)
   static constexpr int Z_LANES = 2 * NW;         // 16-B pieces of the BN/8 zero words
   static constexpr int SET_BYTES = 16 * (SC_LANES + Z_LANES);
-  static constexpr int A_IMG_BYTES = MT * 4096;  // MT x 4 operand images of 1 KiB
+  static constexpr int A_HALF_BYTES = MT * 4096; // one 128-k half: MT x 4 operand images of 1 KiB
+  static constexpr int A_IMG_BYTES = (BK / 128) * A_HALF_BYTES;
   static constexpr int A_BYTES = A_IMG_BYTES + SETS * SET_BYTES;  // A-ring slot: images + sets
   // ring depths: the weight stream comes from HBM (~2-3 us under load) and needs >= 48 KiB in
   // flight per CU; activations / scales come from L2 and need two stages ahead.
 #ifdef STRIPE_DEEP
   static constexpr int W_DEPTH = NW == 2 ? 8 : 5;
   static constexpr int A_DEPTH = 3;
-  static constexpr int WAVES_PER_SIMD = 2;
+  static constexpr int WAVES_PER_SIMD = WV / 4;
 #else
 #ifndef STRIPE_AD
 #define STRIPE_AD 3
 #endif
   static constexpr int W_DEPTH = 3;
   static constexpr int A_DEPTH = STRIPE_AD;
-  static constexpr int WAVES_PER_SIMD = 2;
+  static constexpr int WAVES_PER_SIMD = WV / 4;
 #endif
   static constexpr int W_COPIES = NW;            // per weight-loader wave (waves 0-3) and stage
   static constexpr int A_COPIES = MT + 1;        // per activation-loader wave (4-7): images + one set
   static constexpr int A_RING = 0;
   static constexpr int W_RING = A_DEPTH * A_BYTES;
   static constexpr int RING_BYTES = W_RING + W_DEPTH * W_BYTES;
-  static constexpr int RED_BYTES = (KW - 1) * NW * MT * 16 * 64 * 4;
+  static constexpr int RED_BYTES = (KW / 2) * NW * MT * 16 * 64 * 4;   // tree reduction: the upper half writes
   static constexpr int LDS_BYTES = RING_BYTES > RED_BYTES ? RING_BYTES : RED_BYTES;
 };
 
@@ -87,13 +97,18 @@ __device__ __forceinline__ void lds_dma16_nt(const void* gptr, uint32_t lds_base
 // first); a stripe is then 64 gate columns (column wave 0) + the 64 matching up columns (column
 // wave 1) and the epilogue writes act[M, ffn] = silu_and_mul(C) (csrc/activation_kernels.cu:14-36
 // applied to the T-rounded accumulators: the bits of awq_gemm followed by silu_and_mul).
-template <typename T, int MT, int NW, int ZMODE, int SETS, bool SILU = false>
-__global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIMD)) void w4a16_gemm_stripe_kernel(
+template <typename T, int MT, int NW, int ZMODE, int SETS, bool SILU = false, int WV = 8>
+__global__ __launch_bounds__((StripeCfg<MT, NW, SETS, WV>::THREADS)) void w4a16_gemm_stripe_kernel(
     T* __restrict__ c, float* __restrict__ slabs, const T* __restrict__ a, int64_t lda,
     const uint32_t* __restrict__ qw, const T* __restrict__ scales, const uint32_t* __restrict__ qz,
     int m, int n, int k, int group, int stages_per_split) {
-  using Cfg = StripeCfg<MT, NW, SETS>;
+  using Cfg = StripeCfg<MT, NW, SETS, WV>;
+  constexpr int kStBK = Cfg::BK;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef STRIPE_STAMP
+  const uint64_t st_entry = __builtin_readcyclecounter();
+  uint64_t st_loop0 = 0, st_loop1 = 0;
+#endif
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -132,8 +147,8 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
 
   // ---- loader roles: the LDS-DMA queue of a wave completes in issue order, so the deep weight
   // ring and the shallow activation ring are fed by different waves (each waits on its own).
-  const bool w_loader = wave < 4;
-  const int lw = wave & 3;
+  const bool w_loader = wave < Cfg::LOADERS;
+  const int lw = wave % Cfg::LOADERS;
   // weights: piece p = 1 KiB = 4/NW packed rows of the stripe; loader lw copies pieces lw*NW ..
   uint32_t w_off[Cfg::W_COPIES];   // byte offset from qw + stage * 16 * n
   {
@@ -159,12 +174,14 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
   // reads row lc, k-group lr of one k-step — the MFMA A operand, conflict-free.
   uint32_t a_off[MT];   // byte offset from a + stage * 128
   {
-    const int r = lane >> 4, ks = ((lane >> 2) & 3) ^ lw, a_lr = (lane & 3) ^ r;
+    // (stages of 256 k: loader lw copies row quad lw & 3 of the 128-k half lw >> 2)
+    const int aj = lw & 3, ah = lw >> 2;
+    const int r = lane >> 4, ks = ((lane >> 2) & 3) ^ aj, a_lr = (lane & 3) ^ r;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      int row = 16 * i + 4 * lw + r;
+      int row = 16 * i + 4 * aj + r;
       row = row < m ? row : m - 1;   // rows >= m only feed accumulator rows that are never stored
-      a_off[i] = (uint32_t)(((int64_t)row * lda + 32 * ks + 8 * a_lr) * sizeof(T));
+      a_off[i] = (uint32_t)(((int64_t)row * lda + 128 * ah + 32 * ks + 8 * a_lr) * sizeof(T));
     }
   }
   // scales + zero points of one set: lanes [0, SC_LANES) fetch scales, the next Z_LANES zeros
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
     const uint32_t sb = lds_base + Cfg::W_RING + slot * Cfg::W_BYTES + lw * Cfg::W_COPIES * 1024;
 #pragma unroll
     for (int j = 0; j < Cfg::W_COPIES; ++j)
-      lds_dma16_s_nt(qw + (int64_t)stage * 16 * n, w_off[j], sb + j * 1024);
+      lds_dma16_s_nt(qw + (int64_t)stage * (kStBK / 8) * n, w_off[j], sb + j * 1024);
   };
   auto issue_a = [&](int slot, int stage) {
 #if defined(STRIPE_ABLATE_DMA) || defined(STRIPE_NO_A)
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
     const uint32_t sb = lds_base + Cfg::A_RING + slot * Cfg::A_BYTES;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
-      lds_dma16_s(a + stage * kStBK, a_off[i], sb + (i * 4 + lw) * 1024);
+      lds_dma16_s(a + stage * kStBK, a_off[i], sb + (lw >> 2) * Cfg::A_HALF_BYTES + (i * 4 + (lw & 3)) * 1024);
     const int g = (stage * kStBK + my_set * (kStBK / SETS)) / group;
     if (sc_lane) lds_dma16(sc_src + (int64_t)g * sc_gstride, sb + Cfg::A_IMG_BYTES + my_set * Cfg::SET_BYTES);
   };
@@ -229,6 +246,145 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
   const int colw = 64 * wn + 4 * lc;       // first of this lane's 4 columns inside the stripe
   const int ncol = gcol(colw);
   int cur_w = 0, cur_a = 0;                // ring slots of stage `it`
+#ifndef STRIPE_NO_PINGPONG
+  // The two waves of a SIMD (w and w + 4) run the loop half an iteration apart, as in the prefill GEMM
+  // (w4a16_unfused.hip): an iteration is {memory cluster: LDS reads of the stage's operands, copies of a
+  // later stage, own copies of stage it+1 retired} barrier {dequant + MFMA on registers} barrier, and waves
+  // 4-7 enter the loop one barrier late.  In phase, both waves of a SIMD sit in their LDS / copy-issue
+  // latencies together and then contend for the vector issue port together.
+  //  * RAW: stage it+1 is first read two barriers after the counted vmcnt that retires a wave's copies of it.
+  //  * WAR: the slot of stage it-1 is re-staged in the memory cluster of stage it; its last reads (waves
+  //    4-7, one epoch earlier) were retired by the lgkmcnt(0) in front of that epoch's barrier.
+  if (w_loader) {
+    if (nst >= Cfg::W_DEPTH - 1) lds_dma_wait<Cfg::W_COPIES * (Cfg::W_DEPTH - 2)>();
+    else lds_dma_wait<0>();
+  } else {
+    if (nst >= Cfg::A_DEPTH - 1) lds_dma_wait<Cfg::A_COPIES * (Cfg::A_DEPTH - 2)>();
+    else lds_dma_wait<0>();
+  }
+  __syncthreads();   // stage 0 is complete in LDS
+  if (!w_loader) __builtin_amdgcn_s_barrier();
+#ifdef STRIPE_STAMP
+  st_loop0 = __builtin_readcyclecounter();
+  uint64_t st_sum[4] = {0, 0, 0, 0};
+#define ST_T(x) const uint64_t x = __builtin_readcyclecounter()
+#else
+#define ST_T(x)
+#endif
+  for (int it = 0; it < nst; ++it) {
+    ST_T(st0);
+    const char* ab = smem + Cfg::A_RING + cur_a * Cfg::A_BYTES;
+    const char* wb = smem + Cfg::W_RING + cur_w * Cfg::W_BYTES;
+    uint2 scq[Cfg::KS_PER_WAVE];
+    uint32_t zq[Cfg::KS_PER_WAVE];
+    uint4 wq[Cfg::KS_PER_WAVE];
+    uint4 af[Cfg::KS_PER_WAVE][MT];
+#pragma unroll
+    for (int q = 0; q < Cfg::KS_PER_WAVE; ++q) {
+      const int ks = wk * Cfg::KS_PER_WAVE + q;
+      const int set = ks / (Cfg::KSTEPS / SETS);
+      const char* setp = ab + Cfg::A_IMG_BYTES + set * Cfg::SET_BYTES;
+      scq[q] = *reinterpret_cast<const uint2*>(setp + colw * 2);
+      zq[q] = *reinterpret_cast<const uint32_t*>(setp + 16 * Cfg::SC_LANES + (colw >> 3) * 4);
+      wq[q] = *reinterpret_cast<const uint4*>(wb + (4 * ks + lr) * Cfg::W_ROW_BYTES + colw * 4);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        af[q][i] = *reinterpret_cast<const uint4*>(ab + (ks >> 2) * Cfg::A_HALF_BYTES + i * 4096 + a_rd +
+                                                   (((ks & 3) ^ (lc >> 2)) << 6));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (w_loader) {
+      const int nxt = it + Cfg::W_DEPTH - 1;   // goes into the slot stage it-1 vacated
+      int slot = cur_w + Cfg::W_DEPTH - 1;
+      slot = slot >= Cfg::W_DEPTH ? slot - Cfg::W_DEPTH : slot;
+      if (nxt < nst) {
+        issue_w(slot, stage_of(nxt));
+        lds_dma_wait<Cfg::W_COPIES * (Cfg::W_DEPTH - 2)>();   // own copies of stage it+1
+      } else {
+        lds_dma_wait<0>();
+      }
+    } else {
+      const int nxt = it + Cfg::A_DEPTH - 1;
+      int slot = cur_a + Cfg::A_DEPTH - 1;
+      slot = slot >= Cfg::A_DEPTH ? slot - Cfg::A_DEPTH : slot;
+      if (nxt < nst) {
+        issue_a(slot, stage_of(nxt));
+        lds_dma_wait<Cfg::A_COPIES * (Cfg::A_DEPTH - 2)>();
+      } else {
+        lds_dma_wait<0>();
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    ST_T(st1);
+    __builtin_amdgcn_s_barrier();
+    ST_T(st2);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef STRIPE_ABLATE_COMPUTE
+    // Software pipeline over the 4*KS_PER_WAVE packed words of the stage: the MFMAs of word j
+    // are issued between the dequant VALU of word j+1 (a lone wave issues a VALU op every ~8
+    // cycles and an MFMA occupies the matrix pipe for 16: back to back they do not overlap).
+    constexpr int NWORDS = 4 * Cfg::KS_PER_WAVE;
+    float scf[Cfg::KS_PER_WAVE][4], zsf[Cfg::KS_PER_WAVE][4];
+#pragma unroll
+    for (int q = 0; q < Cfg::KS_PER_WAVE; ++q) {
+      T sct[4];
+      *reinterpret_cast<uint2*>(sct) = scq[q];
+      float zp[4];
+      unpack_zeros4<ZMODE>(zq[q], ncol, zp);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        scf[q][t] = to_f32(sct[t]);
+        zsf[q][t] = -zp[t] * scf[q][t];
+      }
+    }
+    auto word_of = [&](int j) {
+      const int q = j >> 2, t = j & 3;
+      return t == 0 ? wq[q].x : (t == 1 ? wq[q].y : (t == 2 ? wq[q].z : wq[q].w));
+    };
+    uint4 bf_cur = dequant_word<T>(word_of(0), scf[0][0], zsf[0][0]);
+#pragma unroll
+    for (int j = 0; j < NWORDS; ++j) {
+      const int q = j >> 2, t = j & 3;
+      uint4 bf_nxt = bf_cur;
+      if (j + 1 < NWORDS) bf_nxt = dequant_word<T>(word_of(j + 1), scf[(j + 1) >> 2][(j + 1) & 3], zsf[(j + 1) >> 2][(j + 1) & 3]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][t] = Mfma<T>::run(af[q][i], bf_cur, acc[i][t]);
+      if (j + 1 < NWORDS) {
+        // interleave: MT groups of {1 MFMA, ceil(19/MT) VALU}
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, (19 + MT - 1) / MT, 0);
+        }
+      }
+      bf_cur = bf_nxt;
+    }
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    ST_T(st3);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef STRIPE_STAMP
+    {
+      const uint64_t st4 = __builtin_readcyclecounter();
+      st_sum[0] += st1 - st0; st_sum[1] += st2 - st1; st_sum[2] += st3 - st2; st_sum[3] += st4 - st3;
+    }
+#endif
+    cur_w = cur_w + 1 == Cfg::W_DEPTH ? 0 : cur_w + 1;
+    cur_a = cur_a + 1 == Cfg::A_DEPTH ? 0 : cur_a + 1;
+  }
+#ifdef STRIPE_STAMP
+  st_loop1 = __builtin_readcyclecounter();
+  if (lane == 0 && blockIdx.x < 8 && gridDim.y == 1 && slabs != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) slabs[(blockIdx.x * 16 + wave) * 8 + i] = (float)st_sum[i] / (float)(nst > 0 ? nst : 1);
+    slabs[(blockIdx.x * 16 + wave) * 8 + 4] = (float)(st_loop0 - st_entry);
+    slabs[(blockIdx.x * 16 + wave) * 8 + 5] = (float)(st_loop1 - st_loop0);
+  }
+#endif
+  if (w_loader) __builtin_amdgcn_s_barrier();
+#else
   for (int it = 0; it < nst; ++it) {
     // stage `it` has landed once only the copies of the stages issued after it are pending
     if (w_loader) {
@@ -250,14 +406,15 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
 #pragma unroll
     for (int q = 0; q < Cfg::KS_PER_WAVE; ++q) {
       const int ks = wk * Cfg::KS_PER_WAVE + q;
-      const int set = ks / (4 / SETS);
+      const int set = ks / (Cfg::KSTEPS / SETS);
       const char* setp = ab + Cfg::A_IMG_BYTES + set * Cfg::SET_BYTES;
       scq[q] = *reinterpret_cast<const uint2*>(setp + colw * 2);
       zq[q] = *reinterpret_cast<const uint32_t*>(setp + 16 * Cfg::SC_LANES + (colw >> 3) * 4);
       wq[q] = *reinterpret_cast<const uint4*>(wb + (4 * ks + lr) * Cfg::W_ROW_BYTES + colw * 4);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
-        af[q][i] = *reinterpret_cast<const uint4*>(ab + i * 4096 + a_rd + ((ks ^ (lc >> 2)) << 6));
+        af[q][i] = *reinterpret_cast<const uint4*>(ab + (ks >> 2) * Cfg::A_HALF_BYTES + i * 4096 + a_rd +
+                                                   (((ks & 3) ^ (lc >> 2)) << 6));
     }
     if (w_loader) {
       const int nxt = it + Cfg::W_DEPTH - 1;   // goes into the slot stage it-1 just vacated
@@ -314,34 +471,34 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
     cur_w = cur_w + 1 == Cfg::W_DEPTH ? 0 : cur_w + 1;
     cur_a = cur_a + 1 == Cfg::A_DEPTH ? 0 : cur_a + 1;
   }
+#endif
 
-  // ---- add the KW K-waves of each column wave through LDS (the rings are dead now) ----
-  __syncthreads();
+  // ---- add the KW K-waves of each column wave through LDS (the rings are dead now): a binary tree, in
+  // every round the upper half of the live K-waves hands its tiles to the lower half (fixed order) ----
   float* red = reinterpret_cast<float*>(smem);
   constexpr int kSlab = MT * 16 * 64;
-  if (wk > 0) {
-    float* dst = red + ((wk - 1) * NW + wn) * kSlab;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+  for (int half = Cfg::KW / 2; half >= 1; half >>= 1) {
+    __syncthreads();   // the rings / the previous round's slabs are dead
+    if (wk >= half && wk < 2 * half) {
+      // slot (i, j) of a tile is lane-linear (a wave instruction moves 1 KiB of consecutive LDS: no bank
+      // conflicts; [row][64 columns] put lanes lr = 0..3 one KiB apart, 4-way conflicts on every access)
+      float4* dst = reinterpret_cast<float4*>(red + ((wk - half) * NW + wn) * kSlab) + lane;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = i * 16 + 4 * lr + j;
-        *reinterpret_cast<float4*>(dst + row * 64 + 4 * lc) =
-            make_float4(acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]);
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          dst[(i * 4 + j) * 64] = make_float4(acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]);
       }
     }
-  }
-  __syncthreads();
-  if (wk == 0) {
-#pragma unroll 1
-    for (int w = 1; w < Cfg::KW; ++w) {
-      const float* src = red + ((w - 1) * NW + wn) * kSlab;
+    __syncthreads();
+    if (wk < half) {
+      const float4* src = reinterpret_cast<const float4*>(red + (wk * NW + wn) * kSlab) + lane;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int row = i * 16 + 4 * lr + j;
-          const float4 v = *reinterpret_cast<const float4*>(src + row * 64 + 4 * lc);
+          const float4 v = src[(i * 4 + j) * 64];
           acc[i][0][j] += v.x;
           acc[i][1][j] += v.y;
           acc[i][2][j] += v.z;
@@ -350,18 +507,20 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
       }
     }
   }
+#ifdef STRIPE_STAMP
+  if (lane == 0 && blockIdx.x < 8 && gridDim.y == 1 && slabs != nullptr)
+    slabs[(blockIdx.x * 16 + wave) * 8 + 6] = (float)(__builtin_readcyclecounter() - st_loop1);   // reduction tree
+#endif
   if constexpr (SILU) {
     // column wave 1 (up) hands its tile to column wave 0 (gate) through LDS: same lane layout
     __syncthreads();                 // all partial sums have been read
     if (wk == 0 && wn == 1) {
+      float4* dst = reinterpret_cast<float4*>(red) + lane;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int row = i * 16 + 4 * lr + j;
-          *reinterpret_cast<float4*>(red + row * 64 + 4 * lc) =
-              make_float4(acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]);
-        }
+        for (int j = 0; j < 4; ++j)
+          dst[(i * 4 + j) * 64] = make_float4(acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]);
       }
     }
     __syncthreads();
@@ -374,7 +533,7 @@ __global__ __launch_bounds__(kStThreads, (StripeCfg<MT, NW, SETS>::WAVES_PER_SIM
       for (int j = 0; j < 4; ++j) {
         const int row = i * 16 + 4 * lr + j;
         if (row >= m) continue;
-        const float4 u = *reinterpret_cast<const float4*>(red + row * 64 + 4 * lc);
+        const float4 u = reinterpret_cast<const float4*>(red)[(i * 4 + j) * 64 + lane];
         const float uu[4] = {u.x, u.y, u.z, u.w};
         T o[4];
 #pragma unroll
@@ -414,7 +573,8 @@ struct StripePlan {
 // Cost model (microseconds) behind the choice of stripe width and K split; constants from
 // /opt/skills/guides/MI355X_MICROARCH.md (per-CU LDS fill ~70 GB/s from L2, HBM ~6.5 TB/s
 // streamed, plain stores ~6 TB/s) and the kernel's ~100 VALU per wave and k-step.
-static StripePlan plan_stripe(int rows, int n, int k, int64_t ws_elems) {
+static StripePlan plan_stripe(int rows, int n, int k, int64_t ws_elems, int bk) {
+  const int kStBK = bk;
   if (const char* f = getenv("MI355X_STRIPE_FORCE")) {   // "nw,sk" (kernel experiments)
     int nw = 2, sk = 1;
     if (sscanf(f, "%d,%d", &nw, &sk) == 2 && (nw == 2 || nw == 4) && sk >= 1) {
@@ -431,11 +591,14 @@ static StripePlan plan_stripe(int rows, int n, int k, int64_t ws_elems) {
   const double wbytes = (double)n * k / 2;
   StripePlan best{0, 1, stages, 1e30};
   for (int nw = 2; nw <= 4; nw += 2) {
+    if (bk == 256 && nw != 2) continue;   // (16 waves: 2 column waves x 8 K waves only)
     const int bn = 64 * nw;
     const int stripes = (n + bn - 1) / bn;
     const double fill = (64.0 * bn + mtt * 4096.0) / 70e3;
     const double valu = nw * 0.17;
-    const double stage_t = fill > valu ? fill : valu;
+    // per stage of bk k: two waves per SIMD (bk 128) are bound by a wave's own instruction stream,
+    // four (bk 256) by the SIMD's vector issue port
+    const double stage_t = (fill > valu ? fill : valu) * (bk == 256 ? STRIPE_T256 : 1.0);
     const int max_sk = stages < 16 ? stages : 16;
     for (int sk = 1; sk <= max_sk; ++sk) {
       const int steps = (stages + sk - 1) / sk;
@@ -454,10 +617,10 @@ static StripePlan plan_stripe(int rows, int n, int k, int64_t ws_elems) {
   return best;
 }
 
-template <typename T, int MT, int NW, int ZMODE, int SETS, bool SILU = false>
+template <typename T, int MT, int NW, int ZMODE, int SETS, bool SILU = false, int WV = 8>
 static int launch_stripe_cfg(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p) {
-  using Cfg = StripeCfg<MT, NW, SETS>;
-  auto kern = w4a16_gemm_stripe_kernel<T, MT, NW, ZMODE, SETS, SILU>;
+  using Cfg = StripeCfg<MT, NW, SETS, WV>;
+  auto kern = w4a16_gemm_stripe_kernel<T, MT, NW, ZMODE, SETS, SILU, WV>;
   static PerDeviceOnce attr_once;  // one per instantiation, one bit per device
   int dev;
   if (attr_once.need(&dev)) {
@@ -471,46 +634,79 @@ static int launch_stripe_cfg(const GemmArgs& g, const T* a, T* c, int rows, cons
     attr_once.mark(dev);
   }
   const int stripes = SILU ? g.n / 128 : (g.n + Cfg::BN - 1) / Cfg::BN;
-  hipLaunchKernelGGL(kern, dim3(stripes, p.sk), dim3(kStThreads), Cfg::LDS_BYTES, g.stream, c, g.ws,
+  hipLaunchKernelGGL(kern, dim3(stripes, p.sk), dim3(Cfg::THREADS), Cfg::LDS_BYTES, g.stream, c, g.ws,
                      a, g.lda, g.qw, static_cast<const T*>(g.scales), g.qz,
                      rows, g.n, g.k, g.group, p.steps);
   return check_launch("w4a16_gemm_stripe");
 }
 
 template <typename T, int MT, int ZMODE, int SETS>
-static int launch_stripe_nw(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p) {
+static int launch_stripe_nw(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p, int wv) {
+#ifdef STRIPE_WV16
+  if (wv == 16) return launch_stripe_cfg<T, MT, 2, ZMODE, SETS, false, 16>(g, a, c, rows, p);
+#endif
+  (void)wv;
   if (p.nw == 2) return launch_stripe_cfg<T, MT, 2, ZMODE, SETS>(g, a, c, rows, p);
   return launch_stripe_cfg<T, MT, 4, ZMODE, SETS>(g, a, c, rows, p);
 }
 
 template <typename T, int ZMODE, int SETS>
-static int launch_stripe_mt(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p) {
+static int launch_stripe_mt(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p, int wv) {
   const int mt = (rows + 15) / 16;
-  if (mt <= 1) return launch_stripe_nw<T, 1, ZMODE, SETS>(g, a, c, rows, p);
-  if (mt <= 2) return launch_stripe_nw<T, 2, ZMODE, SETS>(g, a, c, rows, p);
-  return launch_stripe_nw<T, 4, ZMODE, SETS>(g, a, c, rows, p);
+  if (mt <= 1) return launch_stripe_nw<T, 1, ZMODE, SETS>(g, a, c, rows, p, wv);
+  if (mt <= 2) return launch_stripe_nw<T, 2, ZMODE, SETS>(g, a, c, rows, p, wv);
+  return launch_stripe_nw<T, 4, ZMODE, SETS>(g, a, c, rows, p, wv);
+}
+
+// waves per workgroup: 16 (stages of 256 k, four waves per SIMD) for long unsplit K loops.  Per 128 k the
+// 16-wave loop takes ~1300 cycles against ~1560 (scripts/stamp_stripe.py), but its prologue (two 48-KiB
+// stages) and its K-wave reduction (8 tiles instead of 4 through LDS) cost ~4.5k cycles more: it pays
+// from ~12 stages of 256 k per workgroup on, i.e. for gate_up, not for the K-split qkv / o / down launches.
+static int stripe_waves(int k, int group, int sk) {
+  static const int forced = [] {
+    const char* e = getenv("MI355X_STRIPE_WV");   // kernel experiments: 8 or 16
+    return e ? atoi(e) : 0;
+  }();
+#ifdef STRIPE_WV16
+  const bool ok16 = k % 256 == 0 && (group % 256 == 0 || group == 128 || group == 64);
+  if (forced == 8 || !ok16) return 8;
+  if (forced == 16) return 16;
+  return sk == 1 && k / 256 >= 12 ? 16 : 8;
+#else
+  // The 16-wave instantiations are compiled only with -DSTRIPE_WV16: with the rule above bench.py measures
+  // 5993 tokens/s against 5994 with 8 waves everywhere (gate_up alone 31.5-33.7 us vs 32.3-35.0).
+  (void)forced; (void)k; (void)group; (void)sk;
+  return 8;
+#endif
+}
+// scale / zero sets per stage of bk k; 0: not a layout this kernel handles
+static int stripe_sets(int group, int bk) {
+  if (group % bk == 0) return 1;
+  if (group < 32 || bk % group != 0) return 0;
+  const int s = bk / group;
+  return s <= 4 ? s : 0;
 }
 
 // returns 1 when the shape / scratch is not one this path handles (caller falls back)
 template <typename T>
 static int run_stripe(const GemmArgs& g, int row0, int rows) {
-  if (rows > 64 || g.k % kStBK != 0 || g.n % 64 != 0 || g.n < 64) return 1;
-  int sets;
-  if (g.group % 128 == 0) sets = 1;
-  else if (g.group == 64) sets = 2;
-  else if (g.group == 32) sets = 4;
-  else return 1;
+  if (rows > 64 || g.k % 128 != 0 || g.n % 64 != 0 || g.n < 64) return 1;
   if ((reinterpret_cast<uintptr_t>(g.qw) & 15) || (reinterpret_cast<uintptr_t>(g.scales) & 15) ||
       (reinterpret_cast<uintptr_t>(g.qz) & 15))
     return 1;
   const T* a = static_cast<const T*>(g.a) + (int64_t)row0 * g.lda;
   T* c = static_cast<T*>(g.c) + (int64_t)row0 * g.n;
   int rc;
-  const StripePlan p = plan_stripe(rows, g.n, g.k, g.ws ? g.ws_elems : 0);
+  StripePlan p = plan_stripe(rows, g.n, g.k, g.ws ? g.ws_elems : 0, 128);
   if (p.nw == 0) return 1;
+  const int wv = p.nw == 2 ? stripe_waves(g.k, g.group, p.sk) : 8;
+  const int bk = 16 * wv;
+  if (wv == 16) p = p.sk == 1 ? StripePlan{2, 1, g.k / bk, 0.0} : plan_stripe(rows, g.n, g.k, g.ws ? g.ws_elems : 0, bk);
+  const int sets = stripe_sets(g.group, bk);
+  if (sets == 0) return 1;
 #define STRIPE_Z(SETSV)                                                              \
-  (g.zmode == kZeroAwq ? launch_stripe_mt<T, kZeroAwq, SETSV>(g, a, c, rows, p)         \
-                       : launch_stripe_mt<T, kZeroGptq, SETSV>(g, a, c, rows, p))
+  (g.zmode == kZeroAwq ? launch_stripe_mt<T, kZeroAwq, SETSV>(g, a, c, rows, p, wv)         \
+                       : launch_stripe_mt<T, kZeroGptq, SETSV>(g, a, c, rows, p, wv))
   rc = sets == 1 ? STRIPE_Z(1) : (sets == 2 ? STRIPE_Z(2) : STRIPE_Z(4));
 #undef STRIPE_Z
   if (rc) return rc;
@@ -531,27 +727,31 @@ static int run_stripe(const GemmArgs& g, int row0, int rows) {
 // stripe.  Returns 1 when not applicable.
 template <typename T>
 static int run_stripe_silu(const GemmArgs& g) {
-  if (g.m > 64 || g.m < 1 || g.k % kStBK != 0 || g.n % 128 != 0 || g.zmode != kZeroAwq) return 1;
-  int sets;
-  if (g.group % 128 == 0) sets = 1;
-  else if (g.group == 64) sets = 2;
-  else if (g.group == 32) sets = 4;
-  else return 1;
+  if (g.m > 64 || g.m < 1 || g.k % 128 != 0 || g.n % 128 != 0 || g.zmode != kZeroAwq) return 1;
+  const int wv = stripe_waves(g.k, g.group, 1);
+  const int bk = 16 * wv;
+  const int sets = stripe_sets(g.group, bk);
+  if (sets == 0) return 1;
   if ((reinterpret_cast<uintptr_t>(g.qw) & 15) || (reinterpret_cast<uintptr_t>(g.scales) & 15) ||
       (reinterpret_cast<uintptr_t>(g.qz) & 15) || (reinterpret_cast<uintptr_t>(g.c) & 7))
     return 1;
   const T* a = static_cast<const T*>(g.a);
   T* c = static_cast<T*>(g.c);
-  const StripePlan p{2, 1, g.k / kStBK, 0.0};
+  const StripePlan p{2, 1, g.k / bk, 0.0};
   const int mt = (g.m + 15) / 16;
-#define STRIPE_S(MTV)                                                                         \
-  (sets == 1 ? launch_stripe_cfg<T, MTV, 2, kZeroAwq, 1, true>(g, a, c, g.m, p)               \
-             : (sets == 2 ? launch_stripe_cfg<T, MTV, 2, kZeroAwq, 2, true>(g, a, c, g.m, p)  \
-                          : launch_stripe_cfg<T, MTV, 2, kZeroAwq, 4, true>(g, a, c, g.m, p)))
+#ifdef STRIPE_WV16
+#define STRIPE_SW(MTV, SETSV)                                                                  \
+  (wv == 16 ? launch_stripe_cfg<T, MTV, 2, kZeroAwq, SETSV, true, 16>(g, a, c, g.m, p)          \
+            : launch_stripe_cfg<T, MTV, 2, kZeroAwq, SETSV, true, 8>(g, a, c, g.m, p))
+#else
+#define STRIPE_SW(MTV, SETSV) launch_stripe_cfg<T, MTV, 2, kZeroAwq, SETSV, true, 8>(g, a, c, g.m, p)
+#endif
+#define STRIPE_S(MTV) (sets == 1 ? STRIPE_SW(MTV, 1) : (sets == 2 ? STRIPE_SW(MTV, 2) : STRIPE_SW(MTV, 4)))
   if (mt <= 1) return STRIPE_S(1);
   if (mt <= 2) return STRIPE_S(2);
   return STRIPE_S(4);
 #undef STRIPE_S
+#undef STRIPE_SW
 }
 
 int w4a16_gemm_stripe_silu_dispatch(const GemmArgs& g, int dtype) {
