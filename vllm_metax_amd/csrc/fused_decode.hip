@@ -34,6 +34,24 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
   const int width = total_heads * head_size;
   T* grow = qkv + token * qkv_stride + c0;
 
+  // position, slot and this thread's cos / sin chunk are fetched up front: behind the slab sum they would
+  // be two more dependent memory round trips of a launch that is nothing but round trips
+  const int embed = head_size / 2;
+  const int cph = embed / V;
+  const int rot_heads = min(h1, num_heads + num_kv_heads) - h0;     // <= 0: v heads only
+  const int64_t slot = slot_mapping[token];
+  Vec16<T> cs0, sn0;
+  const bool pre = rot_heads > 0 && (int)threadIdx.x < rot_heads * cph;
+  const T* cos_ptr = nullptr;
+  if (rot_heads > 0) {
+    cos_ptr = cos_sin_cache + positions[token] * head_size;
+    if (pre) {
+      const int c = (int)threadIdx.x % cph;
+      cs0 = load16(cos_ptr + c * V);
+      sn0 = load16(cos_ptr + embed + c * V);
+    }
+  }
+
   // 1. the columns, as T
   for (int i = threadIdx.x * V; i < cols; i += blockDim.x * V) {
     if (sk > 0) {
@@ -50,12 +68,7 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
   __syncthreads();
 
   // 2. NeoX rotary on the q and k heads (rot_dim == head_size), in LDS
-  const int embed = head_size / 2;
-  const int cph = embed / V;
-  const int rot_heads = min(h1, num_heads + num_kv_heads) - h0;     // <= 0: v heads only
   if (rot_heads > 0) {
-    const int64_t pos = positions[token];
-    const T* cos_ptr = cos_sin_cache + pos * head_size;
     const T* sin_ptr = cos_ptr + embed;
     for (int i = threadIdx.x; i < rot_heads * cph; i += blockDim.x) {
       const int h = i / cph;
@@ -63,8 +76,9 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
       T* base = row + h * head_size;
       Vec16<T> x = load16(base + c * V);
       Vec16<T> y = load16(base + embed + c * V);
-      const Vec16<T> cs = load16(cos_ptr + c * V);
-      const Vec16<T> sn = load16(sin_ptr + c * V);
+      const bool first = i == (int)threadIdx.x;                 // (the chunk fetched up front)
+      const Vec16<T> cs = first ? cs0 : load16(cos_ptr + c * V);
+      const Vec16<T> sn = first ? sn0 : load16(sin_ptr + c * V);
 #pragma unroll
       for (int j = 0; j < V; ++j) rot_pair<T>(x.e[j], y.e[j], cs.e[j], sn.e[j]);
       store16(base + c * V, x);
@@ -78,7 +92,6 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
   for (int i = threadIdx.x * V; i < back * head_size; i += blockDim.x * V) {
     store16(grow + i, load16(row + i));
   }
-  const int64_t slot = slot_mapping[token];
   if (slot < 0) return;
   const int64_t blk = slot / block_size;
   const int t = (int)(slot - blk * block_size);

@@ -39,6 +39,17 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
 
   float x[MAXC][V];
   float ss = 0.f;
+  // the weights are fetched with the row (not after the reduction: a decode-sized launch is a chain of
+  // memory round trips, and this one would be the second)
+  T wreg[MAXC][V];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int idx = (c * nthreads + tid) * V;
+    if (idx < hidden_size) {
+      if constexpr (V > 1) *reinterpret_cast<uint4*>(wreg[c]) = *reinterpret_cast<const uint4*>(weight + idx);
+      else wreg[c][0] = weight[idx];
+    }
+  }
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
     const int idx = (c * nthreads + tid) * V;
@@ -92,16 +103,10 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
   for (int c = 0; c < MAXC; ++c) {
     const int idx = (c * nthreads + tid) * V;
     if (idx < hidden_size) {
-      T wv[V];
-      if constexpr (V > 1) {
-        *reinterpret_cast<uint4*>(wv) = *reinterpret_cast<const uint4*>(weight + idx);
-      } else {
-        wv[0] = weight[idx];
-      }
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         const T n = from_f32<T>(x[c][j] * inv_rms);
-        const T o = mul_t<T>(n, wv[j]);
+        const T o = mul_t<T>(n, wreg[c][j]);
         x[c][j] = to_f32(o);
         amax = fmaxf(amax, fabsf(x[c][j]));
       }
