@@ -26,8 +26,6 @@
 //     verbatim as well; a lane's MFMA fragment is 8 bytes of K (ds_read_b64) or 4 + 4 bytes of V,
 //     converted exactly to scalar_t in registers (v_cvt_scalef32_pk_*_fp8, scale 1); k_scale is
 //     folded into the softmax scale and v_scale into the final 1/l.
-#include <cstdlib>
-
 #include "common.cuh"
 
 namespace mi355x {
@@ -67,15 +65,6 @@ struct MfmaQK<f16_t> {
         __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true)));
   }
 };
-
-// keep the first `valid` (may be <= 0 or >= 4) 16-bit elements of a 4-element vector
-__device__ __forceinline__ uint2 zero_tail4(uint2 v, int valid) {
-  if (valid >= 4) return v;
-  if (valid <= 0) return make_uint2(0u, 0u);
-  if (valid == 1) return make_uint2(v.x & 0xFFFFu, 0u);
-  if (valid == 2) return make_uint2(v.x, 0u);
-  return make_uint2(v.x, v.y & 0xFFFFu);
-}
 
 // all-reduce over the four 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48) in registers: gfx950's
 // v_permlane16_swap / v_permlane32_swap exchange row pairs / wave halves (vdst's odd rows with src's even rows;
@@ -243,6 +232,31 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     }
 
     const int t0 = tile * kPfKvTile;
+    if (t0 + kPfKvTile > seq_len) {
+      // last stage of the sequence: zero the V entries of keys >= seq_len once, in LDS (their probabilities are
+      // exactly 0, and 0 * NaN must not reach O) — masking them inside the PV loop put a full lgkmcnt(0) and the
+      // zeroing code behind every fragment read.  Thread -> row tid & 127 of V block tid >> 7.
+      const int bi = tid >> 7;
+      const int kvalid = seq_len - (t0 + 16 * bi);          // keys [0, kvalid) of this block are real
+      char* vimg = reinterpret_cast<char*>(lds + cur * kStageVec) + 2 * kBlkBytes + bi * kBlkBytes;
+      if constexpr (!KV8) {
+        uint32_t* vrow = reinterpret_cast<uint32_t*>(vimg + (tid & 127) * 32);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          if (2 * w >= kvalid) vrow[w] = 0u;
+          else if (2 * w + 1 >= kvalid) vrow[w] &= 0xFFFFu;
+        }
+      } else {
+        uint32_t* vrow = reinterpret_cast<uint32_t*>(vimg + (tid & 127) * 16);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int live = kvalid - 4 * w;                    // live bytes of this dword
+          if (live <= 0) vrow[w] = 0u;
+          else if (live < 4) vrow[w] &= (1u << (8 * live)) - 1u;
+        }
+      }
+      __syncthreads();
+    }
     if (t0 <= wave_q_hi) {
       const uint4* kbuf = lds + cur * kStageVec;
       const uint2* vbuf = reinterpret_cast<const uint2*>(lds + cur * kStageVec + 512);
@@ -323,7 +337,6 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
         pfrag[qt].w = MfmaQK<T>::pack(p[6], p[7]);
       }
       // ---- O^T += V^T . P^T ------------------------------------------------------------
-      const bool tail = (t0 + kPfKvTile) > seq_len;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
         // V block image [128 d][16 keys]: row 16*dt + lc, keys 4*lr..4*lr+3 -> 8 bytes
@@ -336,10 +349,6 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
               sbuf + 4096 + (16 * dt + lc) * 16 + 4 * lr));
           v1 = MfmaQK<T>::from_fp8x4(*reinterpret_cast<const uint32_t*>(
               sbuf + 6144 + (16 * dt + lc) * 16 + 4 * lr));
-        }
-        if (tail) {  // keys >= seq_len may hold NaN garbage: 0 * NaN must not reach O
-          v0 = zero_tail4(v0, seq_len - (t0 + 4 * lr));
-          v1 = zero_tail4(v1, seq_len - (t0 + 16 + 4 * lr));
         }
         const uint4 vf = make_uint4(v0.x, v0.y, v1.x, v1.y);
 #pragma unroll
@@ -356,340 +365,6 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     l = rows_sum(l);
     float inv = 1.0f / l;
     if constexpr (KV8) inv *= *v_scale;
-    if (qrow[qt] < q_len) {
-      T* op = out + (int64_t)(q_begin + qrow[qt]) * out_stride + (int64_t)head * kPfD + 4 * lr;
-#pragma unroll
-      for (int dt = 0; dt < 8; ++dt) {
-        const uint2 v = make_uint2(MfmaQK<T>::pack(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv),
-                                   MfmaQK<T>::pack(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv));
-        *reinterpret_cast<uint2*>(op + 16 * dt) = v;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// Long prompts (max_query_len > 128, scalar_t cache): 8 waves x 32 query rows = 256 rows per workgroup and
-// stages of 64 keys (4 cache blocks of K + 4 of V = 32 KiB), ring of 4 stages.  Against the kernel above
-// (in-kernel s_memtime stamps: per wave and 32-key stage 1900 cycles in wait + barrier + copy issue, 480 in
-// QK^T, 1020 in the softmax, 1260 in PV for 2 x 256 cycles of MFMA):
-//   * a stage feeds twice the rows and twice the keys: half the copies per wave and half the barriers per
-//     MFMA, the row maximum / rescale bookkeeping of the softmax is paid per 64 keys;
-//   * V fragments are ONE ds_read_b128 per (d tile, 32-key chunk) instead of two ds_read_b64: the PV operand
-//     of lane (lr, lc) is 8 CONSECUTIVE keys 8 lr .. 8 lr + 7 of the chunk, 16 contiguous bytes of one row of
-//     a V block image;
-//   * for P^T to come out of the QK^T MFMAs in that key order, row r of S^T tile b of a chunk is key
-//     8 (r >> 2) + 4 b + (r & 3) — the K fragment read gathers its 16 rows from both cache blocks of the chunk —
-//     and the K image is stored with key slot ^= 4 (d-chunk & 1) so that the gather stays bank-conflict-free
-//     (the LDS side of a copy is lane-linear: the swizzle is in WHICH 16 bytes a lane fetches);
-//   * keys >= seq_len of the last stage (NaN garbage of the cache) are zeroed in the V image in LDS once,
-//     not masked in every fragment read: with the test inside the PV loop every read is followed by a full
-//     lgkmcnt(0) and ~100 instructions of zeroing code between two MFMAs.
-constexpr int kP8QTile = 256;
-constexpr int kP8KvTile = 64;
-constexpr int kP8Stages = 4;
-constexpr int kP8StageBytes = 8 * 4096;
-
-template <typename T>
-__global__ __launch_bounds__(512, 2) void paged_prefill_d128_w8_kernel(
-    T* __restrict__ out, const T* __restrict__ q, const void* __restrict__ k_cache_v,
-    const void* __restrict__ v_cache_v, int num_heads, int num_kv_heads, float scale,
-    const int* __restrict__ block_tables, const int* __restrict__ seq_lens,
-    const int* __restrict__ cu_seqlens_q, int max_num_blocks_per_seq, int q_blocks_per_seq,
-    int64_t q_stride, int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const char* k_cache = static_cast<const char*>(k_cache_v);
-  const char* v_cache = static_cast<const char*>(v_cache_v);
-
-  // heaviest query blocks first (see above); 1-D grid: (reversed query block, head, sequence)
-  const int num_seqs_g = (int)gridDim.x / (q_blocks_per_seq * num_heads);
-  const int per_qb = num_heads * num_seqs_g;
-  const int qb = q_blocks_per_seq - 1 - (int)blockIdx.x / per_qb;
-  const int rem = (int)blockIdx.x - (q_blocks_per_seq - 1 - qb) * per_qb;
-  const int head = rem / num_seqs_g;
-  const int seq = rem - head * num_seqs_g;
-  const int q_begin = cu_seqlens_q[seq];
-  const int q_len = cu_seqlens_q[seq + 1] - q_begin;
-  const int m0 = qb * kP8QTile;
-  if (m0 >= q_len) return;
-  const int seq_len = seq_lens[seq];
-  const int ctx = seq_len - q_len;
-  const int kv_head = head / (num_heads / num_kv_heads);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lc = lane & 15;
-  const int lr = lane >> 4;
-
-  uint4 qf[2][4];
-  int qrow[2];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    qrow[qt] = m0 + wave * 32 + qt * 16 + lc;
-    const int r = qrow[qt] < q_len ? qrow[qt] : q_len - 1;
-    const T* qp = q + (int64_t)(q_begin + r) * q_stride + (int64_t)head * kPfD + 8 * lr;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = *reinterpret_cast<const uint4*>(qp + 32 * ds);
-  }
-  f32x4_t oacc[2][8];
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) oacc[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-  float mrun[2] = {kNegBig, kNegBig};
-  float lrun[2] = {0.f, 0.f};
-
-  const int kv_end = min(seq_len, ctx + m0 + kP8QTile);
-  const int num_tiles = (kv_end + kP8KvTile - 1) / kP8KvTile;
-  const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
-  const int num_seq_blocks = (seq_len + kPfBS - 1) / kPfBS;
-  const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-  int bt_reg = 0;
-  int bt_base = -64;
-  auto block_id = [&](int blk) {
-    if (blk >= bt_base + 64 || blk < bt_base) {
-      bt_base = blk & ~63;
-      const int i = bt_base + lane;
-      bt_reg = block_table[i < num_seq_blocks ? i : num_seq_blocks - 1];
-    }
-    return (int64_t)__builtin_amdgcn_readlane(bt_reg, blk - bt_base);
-  };
-  // stage image = [K blk 0..3 | V blk 0..3], 4 KiB each; 32 pieces of 1 KiB, wave w copies pieces of block
-  // 2 i + (w >> 2) (i = 0..3), bytes [1024 (w & 3), +1024) of it.  K pieces: lane l lands in slot (d-chunk
-  // 4 (w & 3) + (l >> 4), position l & 15) and fetches key (l & 15) ^ 4 ((l >> 4) & 1) of that chunk.
-  const int part = wave & 3;
-  const int k_src = part * 1024 + 256 * (lane >> 4) + 16 * ((lane & 15) ^ (4 * ((lane >> 4) & 1)));
-  const int v_src = part * 1024 + lane * 16;
-  auto stage_issue = [&](int slot, int tile) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int bi = 2 * i + (wave >> 2);            // 0..3: K blocks, 4..7: V blocks
-      int blk = tile * 4 + (bi & 3);
-      blk = blk < num_seq_blocks ? blk : num_seq_blocks - 1;
-      const int64_t pb = block_id(blk);
-      const char* base = (bi < 4 ? k_cache : v_cache) +
-                         (pb * kv_block_stride + (int64_t)kv_head * kv_head_stride) * (int64_t)sizeof(T);
-      lds_dma16(base + (bi < 4 ? k_src : v_src), lds_base + slot * kP8StageBytes + bi * 4096 + part * 1024);
-    }
-  };
-#pragma unroll
-  for (int s = 0; s < kP8Stages - 1; ++s) {
-    if (s < num_tiles) stage_issue(s, s);
-  }
-
-  const float sl2 = scale * 1.4426950408889634f;
-  const int wave_limit_lo = min(ctx + m0 + wave * 32, seq_len - 1);
-  const int wave_q_hi = ctx + m0 + wave * 32 + 31;
-  // K fragment of S^T tile b (of either 32-key chunk): row lc <-> chunk key 8 (lc >> 2) + 4 b + (lc & 3)
-  int k_rd[2];
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int keyin = (8 * ((lc >> 2) & 1) + 4 * b + (lc & 3)) ^ (4 * (lr & 1));
-    k_rd[b] = (lc >> 3) * 4096 + lr * 256 + keyin * 16;
-  }
-  // V fragment: row 16 dt + lc of block (lr >> 1) of the chunk, keys 8 (lr & 1) .. + 7
-  const int v_rd = 4 * 4096 + (lr >> 1) * 4096 + lc * 32 + 16 * (lr & 1);
-
-  f32x4_t s[2][2][2];   // S^T tiles s[kk][b][qt]: rows = keys t0 + 32 kk + 8 lr + 4 b + j, column = query lc
-  uint4 pfrag[2][2];
-  auto qk = [&](const char* sb) {
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) s[kk][b][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ds = 0; ds < 4; ++ds) {
-          const uint4 kf = *reinterpret_cast<const uint4*>(sb + kk * 8192 + ds * 1024 + k_rd[b]);
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt) s[kk][b][qt] = MfmaQK<T>::run(kf, qf[qt][ds], s[kk][b][qt]);
-        }
-      }
-    }
-  };
-  // online softmax per query column over the 16 keys of the lane (same arithmetic as the kernel above)
-  auto softmax = [&](int t0) {
-    const bool need_mask = (t0 + kP8KvTile - 1) > wave_limit_lo;
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-      float v[16];
-      if (need_mask) {
-        const int limit = min(ctx + qrow[qt], seq_len - 1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int key = t0 + 32 * kk + 8 * lr + 4 * b + j;
-              v[kk * 8 + b * 4 + j] = key <= limit ? s[kk][b][qt][j] : kNegBig;
-            }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[kk * 8 + b * 4 + j] = s[kk][b][qt][j];
-          }
-        }
-      }
-      float tmax = v[0];
-#pragma unroll
-      for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, v[i]);
-      tmax = rows_max(tmax);
-      const float mnew = fmaxf(mrun[qt], tmax);
-      const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * sl2);
-      mrun[qt] = mnew;
-      const float mc = -mnew * sl2;
-      float p[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) p[i] = __builtin_amdgcn_exp2f(fmaf(v[i], sl2, mc));
-      float psum = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; i += 4) psum += (p[i] + p[i + 1]) + (p[i + 2] + p[i + 3]);
-      lrun[qt] = lrun[qt] * alpha + psum;
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-          oacc[qt][dt][0] *= alpha;
-          oacc[qt][dt][1] *= alpha;
-          oacc[qt][dt][2] *= alpha;
-          oacc[qt][dt][3] *= alpha;
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        pfrag[qt][kk].x = MfmaQK<T>::pack(p[kk * 8 + 0], p[kk * 8 + 1]);
-        pfrag[qt][kk].y = MfmaQK<T>::pack(p[kk * 8 + 2], p[kk * 8 + 3]);
-        pfrag[qt][kk].z = MfmaQK<T>::pack(p[kk * 8 + 4], p[kk * 8 + 5]);
-        pfrag[qt][kk].w = MfmaQK<T>::pack(p[kk * 8 + 6], p[kk * 8 + 7]);
-      }
-    }
-  };
-  auto pv = [&](const char* sb) {   // O^T += V^T . P^T
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const uint4 vf = *reinterpret_cast<const uint4*>(sb + v_rd + kk * 8192 + dt * 512);
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) oacc[qt][dt] = MfmaQK<T>::run(vf, pfrag[qt][kk], oacc[qt][dt]);
-      }
-    }
-  };
-  // last stage of the sequence: zero the V entries of keys >= seq_len (their probabilities are exactly 0, and
-  // 0 * NaN must not reach O).  256 threads (tl = 0..255) do the whole image: rows tl & 127 of blocks tl >> 7, + 2.
-  auto zero_dead_keys = [&](char* sb, int t0, int tl) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int bi = (tl >> 7) + 2 * h;
-      const int kvalid = seq_len - (t0 + 16 * bi);          // keys [0, kvalid) of this block are real
-      uint32_t* vrow = reinterpret_cast<uint32_t*>(sb + 4 * 4096 + bi * 4096 + (tl & 127) * 32);
-#pragma unroll
-      for (int w = 0; w < 8; ++w) {
-        if (2 * w >= kvalid) vrow[w] = 0u;
-        else if (2 * w + 1 >= kvalid) vrow[w] &= 0xFFFFu;
-      }
-    }
-  };
-  auto next_slot = [&](int c, int d) {
-    const int sl = c + d;
-    return sl >= kP8Stages ? sl - kP8Stages : sl;
-  };
-
-  int cur = 0;
-#ifndef P8_PIPELINED
-  // all 8 waves in phase, one barrier per stage: 155-159 us at the bench's prefill chunk (8 x 1024 tokens, 32 / 8
-  // heads), the 4-wave kernel above 189-198.  Per wave and 64-key stage (stamps): ~2600-3600 cycles in QK^T +
-  // softmax, ~720 in PV, the rest waiting for the slower SIMD partner at the barrier; the softmax (~230 VALU + 32
-  // v_exp_f32 per wave and stage) holds the vector issue port longer than the 64 MFMAs hold the matrix pipe.
-  for (int tile = 0; tile < num_tiles; ++tile) {
-    // stage `tile` has landed once only the copies of the (up to two) later stages are pending
-    if (tile + 2 < num_tiles) lds_dma_wait<8>();
-    else if (tile + 1 < num_tiles) lds_dma_wait<4>();
-    else lds_dma_wait<0>();
-    __syncthreads();   // everybody's share of stage `tile` is in LDS; stage tile-1 is dead
-    if (tile + kP8Stages - 1 < num_tiles) stage_issue(next_slot(cur, kP8Stages - 1), tile + kP8Stages - 1);
-    const int t0 = tile * kP8KvTile;
-    char* sb = smem + cur * kP8StageBytes;
-    if (t0 + kP8KvTile > seq_len) {
-      if (tid < 256) zero_dead_keys(sb, t0, tid);
-      __syncthreads();
-    }
-    if (t0 <= wave_q_hi) {
-      qk(sb);
-      softmax(t0);
-      pv(sb);
-    }
-    cur = next_slot(cur, 1);
-  }
-#else
-  // (-DP8_PIPELINED; measured SLOWER, 179 us: with the groups out of phase only ONE wave of a SIMD is in its
-  //  softmax at a time, and a lone wave issues a VALU instruction every ~7 cycles instead of sharing the port at
-  //  ~3.5 — the MFMA partner finishes early and idles.  Two waves per SIMD cannot have both "two waves in the
-  //  VALU phase" and "a partner in the MFMA phase"; four do not fit: 196 VGPRs.)
-  // Software-pipelined ping-pong: a wave's iteration is {softmax of stage t} barrier {PV of stage t, QK^T of stage
-  // t+1, copies of stage t+3} barrier, and waves 4-7 (group 1, the SIMD partners of waves 0-3) enter the loop one
-  // barrier late — while one wave of a SIMD is in its softmax (VALU) the other is in its 64 MFMAs.  Barrier
-  // epochs: group 0 runs its first half of stage t in epoch 2t, group 1 in 2t+1.
-  //  * stage u is read from epoch 2u-1 (K, by group 0) to epoch 2u+2 (V, by group 1); every read is retired by
-  //    the lgkmcnt(0) in front of the barrier that ends its epoch.
-  //  * WAR: stage t+3 takes the slot of stage t-1 (last read in epoch 2t): issued in the second halves of stage t
-  //    (epochs 2t+1 / 2t+2).
-  //  * RAW: a wave retires its own copies of stage u (counted vmcnt) before the barrier that ends epoch 2u-2:
-  //    group 0 at the end of its first half of stage u-1, group 1 at the end of its second half of stage u-2.
-  const bool g1 = wave >= 4;
-  if (num_tiles > 2) lds_dma_wait<4>();        // own copies of stages 0 and 1
-  else lds_dma_wait<0>();
-  __syncthreads();
-  if (0 <= wave_q_hi) qk(smem);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if (g1) __builtin_amdgcn_s_barrier();
-  for (int tile = 0; tile < num_tiles; ++tile) {
-    const int t0 = tile * kP8KvTile;
-    char* sb = smem + cur * kP8StageBytes;
-    const bool active = t0 <= wave_q_hi;
-    // ---- first half: softmax (each group zeroes the dead keys for itself: idempotent)
-    if (t0 + kP8KvTile > seq_len) zero_dead_keys(sb, t0, tid & 255);
-    if (active) softmax(t0);
-    if (!g1) {   // own copies of stage tile+1
-      if (tile + 2 < num_tiles) lds_dma_wait<4>();
-      else lds_dma_wait<0>();
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- second half: the MFMAs
-    __builtin_amdgcn_s_setprio(1);
-    if (active) pv(sb);
-    if (tile + 1 < num_tiles && t0 + kP8KvTile <= wave_q_hi) qk(smem + next_slot(cur, 1) * kP8StageBytes);
-    __builtin_amdgcn_s_setprio(0);
-    if (tile + kP8Stages - 1 < num_tiles) stage_issue(next_slot(cur, kP8Stages - 1), tile + kP8Stages - 1);
-    if (g1) {    // own copies of stage tile+2
-      if (tile + 3 < num_tiles) lds_dma_wait<4>();
-      else lds_dma_wait<0>();
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    cur = next_slot(cur, 1);
-  }
-  if (!g1) __builtin_amdgcn_s_barrier();
-#endif
-
-#pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    float l = lrun[qt];
-    l = rows_sum(l);
-    const float inv = 1.0f / l;
     if (qrow[qt] < q_len) {
       T* op = out + (int64_t)(q_begin + qrow[qt]) * out_stride + (int64_t)head * kPfD + 4 * lr;
 #pragma unroll
@@ -821,34 +496,6 @@ extern "C" int mi355x_paged_prefill_attention(
                       reinterpret_cast<uintptr_t>(value_cache)) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
                     kv_block_stride % (kv8 ? 16 : 8) == 0 && kv_head_stride % (kv8 ? 16 : 8) == 0;
-  static const bool w8_off = [] {
-    const char* e = getenv("MI355X_PREFILL_W8");   // kernel experiments: "0" = the 4-wave kernel everywhere
-    return e && e[0] == '0';
-  }();
-  if (fast && !kv8 && max_query_len > kPfQTile && !w8_off) {
-    const int q_blocks = (max_query_len + kP8QTile - 1) / kP8QTile;
-    dim3 grid(num_seqs * q_blocks * num_heads), block(512);
-    const size_t smem = (size_t)kP8Stages * kP8StageBytes;   // 128 KiB
-    return MI355X_DISPATCH_HALF(dtype, [&] {
-      auto kern = paged_prefill_d128_w8_kernel<scalar_t>;
-      static PerDeviceOnce attr_once;   // one per instantiation, one bit per device
-      int dev;
-      if (attr_once.need(&dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) {
-          set_error("paged_prefill_attention: cannot reserve %zu B of LDS: %s", smem, hipGetErrorString(e));
-          return (int)MI355X_EUNSUPPORTED;
-        }
-        attr_once.mark(dev);
-      }
-      hipLaunchKernelGGL(kern, grid, block, smem, s, static_cast<scalar_t*>(out),
-                         static_cast<const scalar_t*>(query), key_cache, value_cache, num_heads, num_kv_heads,
-                         scale, block_tables, seq_lens, cu_seqlens_q, max_num_blocks_per_seq, q_blocks,
-                         q_stride, out_stride, kv_block_stride, kv_head_stride);
-      return check_launch("paged_prefill_attention");
-    });
-  }
   if (fast) {
     const int q_blocks = (max_query_len + kPfQTile - 1) / kPfQTile;
     dim3 grid(num_seqs * q_blocks * num_heads), block(256);
