@@ -406,17 +406,13 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   auto load_v = [&](int blk, uint4 (&vv)[NIV]) {
     const int64_t pb = bt_s[blk - start_block];
     const CT* vp = v_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
-    const bool last = (blk == num_seq_blocks - 1);
+    // (the tail of the last block is masked in pv_block, in ONE branch behind all the loads: a test here made
+    //  hipcc branch around every load with a full vmcnt(0) behind it — the NIV loads of a block, and the two
+    //  prefetched blocks in front of the softmax, then went to memory one after the other)
 #pragma unroll
     for (int i = 0; i < NIV; ++i) {
       const int d = dsub + DPI0 * i;
-      if (d < D) {
-        uint4 v = ld_kv16(vp + (int64_t)d * BS + tq * X);
-        if (last) v = mask_tail<CT>(v, blk * BS + tq * X, seq_len);
-        vv[i] = v;
-      } else {
-        vv[i] = make_uint4(0, 0, 0, 0);
-      }
+      vv[i] = (d < D) ? ld_kv16(vp + (int64_t)d * BS + tq * X) : make_uint4(0, 0, 0, 0);
     }
   };
   uint4 vpre0[NIV], vpre1[NIV];
@@ -468,7 +464,11 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
     for (int i = 0; i < NIV; ++i) oacc[g][i] = 0.f;
   }
 
-  auto pv_block = [&](int blk, const uint4 (&vv)[NIV]) {
+  auto pv_block = [&](int blk, uint4 (&vv)[NIV]) {
+    if (blk == num_seq_blocks - 1) {   // tokens >= seq_len of the last block: garbage (0 * NaN must not reach O)
+#pragma unroll
+      for (int i = 0; i < NIV; ++i) vv[i] = mask_tail<CT>(vv[i], blk * BS + tq * X, seq_len);
+    }
     uint4 pr[GT][QP];
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
