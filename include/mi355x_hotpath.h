@@ -432,6 +432,18 @@ int mi355x_qkv_rope_cache(void* qkv, int64_t qkv_stride, const float* slabs, int
                           int64_t key_block_stride, int64_t value_block_stride, int dtype,
                           mi355x_stream stream);
 
+/* greedy_advance: the bookkeeping between two greedy decode steps, one launch (the reference has no op
+ * for it: upstream vLLM's sampler and model runner do it with torch ops — argmax, three in-place adds and
+ * the block-table gather that yields slot_mapping; ~13 launches, ~100 us per step at vocab 128256):
+ *   tokens[r] = argmax(logits[r, :vocab])              (lowest index among equal maxima)
+ *   positions[r] += 1; seq_lens[r] += 1
+ *   slot_mapping[r] = block_tables[r][positions[r] / block_size] * block_size + positions[r] % block_size
+ * block_tables [num_seqs][max_num_blocks_per_seq] int32, row r = sequence r of the batch. */
+int mi355x_greedy_advance(const void* logits, int64_t logits_stride, int num_seqs, int vocab,
+                          int64_t* tokens, int64_t* positions, int* seq_lens, int64_t* slot_mapping,
+                          const int* block_tables, int max_num_blocks_per_seq, int block_size,
+                          int dtype, mi355x_stream stream);
+
 /* ----------------------------------------------------------------- fp8 GEMM --
  * out[M,N] (bf16/f16) = (a_scales . a[M,K] e4m3fn row-major) x
  *                       (b_scales . b[K,N] e4m3fn COLUMN-major, ldb = b.stride(1))

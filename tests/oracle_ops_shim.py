@@ -103,3 +103,12 @@ def awq_gemm_silu_mul(x, qweight, qzeros, scales) -> Optional[torch.Tensor]:
 
 def awq_gemm_silu_mul_packed(x, qweight, qzeros, scales):
     return None
+
+
+def greedy_advance(logits, tokens, positions, seq_lens, slot_mapping, block_tables, block_size):
+    tokens.copy_(logits.float().argmax(dim=-1))
+    positions.add_(1)
+    seq_lens.add_(1)
+    bi = (positions // block_size).clamp(max=block_tables.shape[1] - 1)
+    blk = block_tables[torch.arange(positions.numel()), bi].long()
+    slot_mapping.copy_(blk * block_size + positions % block_size)

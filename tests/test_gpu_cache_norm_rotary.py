@@ -452,3 +452,42 @@ def test_silu_and_mul_quant(dtype, d_, tokens):
     out2 = torch.empty_like(out)
     torch.ops._C.silu_and_mul_quant(out2, xd, tiny)
     assert torch.equal(out.view(torch.uint8), out2.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("n,vocab", [(64, 128256), (3, 1000), (1, 7), (5, 4099)])
+def test_greedy_advance(dtype, n, vocab):
+    """MI355X-side decode fusion (no reference op): argmax (lowest index among equal maxima) + positions /
+    seq_lens += 1 + the next slot from the block table, against the torch ops it replaces."""
+    g = torch.Generator().manual_seed(n * 131 + vocab)
+    logits = torch.randn(n, vocab, generator=g).to(dtype)
+    # ties: the same maximum at several places of a row (and across the 16-byte chunk / wave boundaries)
+    for r in range(n):
+        cols = torch.randint(0, vocab, (4,), generator=g)
+        logits[r, cols] = 9.0
+    bs, max_blocks = 16, 12
+    bt = torch.randperm(n * max_blocks, generator=g).to(torch.int32).view(n, max_blocks)
+    pos = torch.randint(0, bs * max_blocks - 1, (n,), generator=g)
+    pos[0] = bs * max_blocks - 1            # a full sequence: the next slot does not exist (index clamped)
+    if n > 1:
+        pos[1] = bs - 1                     # the next token opens a new block
+    seq = (pos + 1).to(torch.int32)
+    d = dev()
+    lg, btd = logits.to(d), bt.to(d)
+    tok = torch.zeros(n, dtype=torch.int64, device=d)
+    posd, seqd = pos.to(d), seq.to(d)
+    slots = torch.zeros(n, dtype=torch.int64, device=d)
+    ops().greedy_advance(lg, tok, posd, seqd, slots, btd, bs)
+    ref_tok = torch.stack([(logits[r].float() == logits[r].float().max()).nonzero()[0, 0] for r in range(n)])
+    assert torch.equal(tok.cpu(), ref_tok)
+    assert torch.equal(posd.cpu(), pos + 1) and torch.equal(seqd.cpu(), seq + 1)
+    npos = pos + 1
+    bi = (npos // bs).clamp(max=max_blocks - 1)
+    ref_slots = bt[torch.arange(n), bi].long() * bs + npos % bs
+    assert torch.equal(slots.cpu()[1:], ref_slots[1:])            # (row 0: no next slot, value unspecified)
+    # a strided logits view (row stride > vocab)
+    wide = torch.zeros(n, vocab + 24, dtype=dtype, device=d)
+    wide[:, :vocab] = lg
+    tok2 = torch.zeros_like(tok)
+    ops().greedy_advance(wide[:, :vocab], tok2, posd, seqd, slots, btd, bs)
+    assert torch.equal(tok2.cpu(), ref_tok)

@@ -689,6 +689,30 @@ def awq_gemm_silu_mul(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.
     return out
 
 
+def greedy_advance(logits: torch.Tensor, tokens: torch.Tensor, positions: torch.Tensor,
+                   seq_lens: torch.Tensor, slot_mapping: torch.Tensor, block_tables: torch.Tensor,
+                   block_size: int) -> None:
+    """MI355X-side decode fusion (no reference op: upstream's sampler / model runner use torch ops): greedy
+    token of every row of `logits` [n, vocab] into `tokens`, positions and seq_lens += 1, slot_mapping =
+    the slot of the new position (block_tables [n, max_blocks] int32, row r = sequence r)."""
+    _dev(logits, tokens, positions, seq_lens, slot_mapping, block_tables)
+    n = logits.size(0)
+    if logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError("greedy_advance: logits must be [n, vocab] with unit inner stride")
+    if tokens.dtype != torch.int64 or positions.dtype != torch.int64 or slot_mapping.dtype != torch.int64 \
+            or seq_lens.dtype != torch.int32 or block_tables.dtype != torch.int32:
+        raise RuntimeError("greedy_advance: tokens / positions / slot_mapping int64, seq_lens / block_tables int32")
+    for t in (tokens, positions, seq_lens, slot_mapping):
+        if t.numel() != n or not t.is_contiguous():
+            raise RuntimeError("greedy_advance: per-sequence tensors must be contiguous with one element per row")
+    if block_tables.dim() != 2 or block_tables.size(0) < n or block_tables.stride(1) != 1:
+        raise RuntimeError("greedy_advance: block_tables must be [>= n, max_blocks]")
+    rc = _abi.load().mi355x_greedy_advance(
+        _ptr(logits), logits.stride(0), n, logits.size(1), _ptr(tokens), _ptr(positions), _ptr(seq_lens),
+        _ptr(slot_mapping), _ptr(block_tables), block_tables.stride(0), int(block_size), _dt(logits), _stream())
+    _abi.check(rc, "greedy_advance")
+
+
 class PackedOperand:
     """An activation matrix [m, k] held as the MFMA operand image the prefill GEMM reads (see
     mi355x_awq_gemm_silu_mul_packed in include/mi355x_hotpath.h): produced by

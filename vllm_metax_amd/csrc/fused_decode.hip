@@ -114,6 +114,58 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
   }
 }
 
+// ---- greedy_advance: what follows the lm_head of a greedy decode step, one launch -----------------
+// token = argmax(logits[row]) (lowest index among equal maxima); position, sequence length += 1; slot of
+// the token the next step writes = block_table[row][new position / block_size] * block_size + remainder.
+// One workgroup per row: lanes stride over 16-byte chunks of the row, (value, index) pairs reduced with
+// max-by-value / min-by-index.
+template <typename T>
+__global__ __launch_bounds__(1024) void greedy_advance_kernel(
+    const T* __restrict__ logits, int64_t logits_stride, int vocab, int64_t* __restrict__ tokens,
+    int64_t* __restrict__ positions, int* __restrict__ seq_lens, int64_t* __restrict__ slot_mapping,
+    const int* __restrict__ block_tables, int max_num_blocks_per_seq, int block_size) {
+  constexpr int V = 16 / sizeof(T);
+  __shared__ float s_val[16];
+  __shared__ int s_idx[16];
+  const int row = blockIdx.x;
+  const T* lr = logits + (int64_t)row * logits_stride;
+  float best = -INFINITY;
+  int bidx = 0x7fffffff;
+  auto take = [&](float v, int i) {
+    if (v > best || (v == best && i < bidx)) best = v, bidx = i;
+  };
+  const bool vec = (reinterpret_cast<uintptr_t>(lr) & 15) == 0;
+  const int nvec = vec ? vocab / V : 0;
+  for (int c = threadIdx.x; c < nvec; c += blockDim.x) {
+    const Vec16<T> x = load16(lr + c * V);
+#pragma unroll
+    for (int j = 0; j < V; ++j) take(to_f32(x.e[j]), c * V + j);
+  }
+  for (int i = nvec * V + threadIdx.x; i < vocab; i += blockDim.x) take(to_f32(lr[i]), i);
+  // wave, then workgroup: (max value, min index among equals)
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const float ov = __shfl_xor(best, m, 64);
+    const int oi = __shfl_xor(bidx, m, 64);
+    take(ov, oi);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) s_val[wave] = best, s_idx[wave] = bidx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w) take(s_val[w], s_idx[w]);
+    tokens[row] = bidx;
+    const int64_t pos = positions[row] + 1;
+    positions[row] = pos;
+    seq_lens[row] += 1;
+    // (a sequence that just filled its last block has no next slot: the index is clamped, the value unused)
+    const int64_t bi = pos / block_size < max_num_blocks_per_seq ? pos / block_size : max_num_blocks_per_seq - 1;
+    const int64_t blk = block_tables[(int64_t)row * max_num_blocks_per_seq + bi];
+    slot_mapping[row] = blk * block_size + pos % block_size;
+  }
+}
+
 }  // namespace mi355x
 
 using namespace mi355x;
@@ -156,5 +208,24 @@ extern "C" int mi355x_qkv_rope_cache(void* qkv, int64_t qkv_stride, const float*
                        static_cast<scalar_t*>(value_cache), slot_mapping, num_heads, num_kv_heads,
                        head_size, block_size, key_block_stride, value_block_stride, hp);
     return check_launch("qkv_rope_cache");
+  });
+}
+
+extern "C" int mi355x_greedy_advance(const void* logits, int64_t logits_stride, int num_seqs, int vocab,
+                                     int64_t* tokens, int64_t* positions, int* seq_lens,
+                                     int64_t* slot_mapping, const int* block_tables,
+                                     int max_num_blocks_per_seq, int block_size, int dtype,
+                                     mi355x_stream stream) {
+  MI355X_REQUIRE(num_seqs >= 0 && vocab > 0 && block_size > 0 && max_num_blocks_per_seq > 0, MI355X_EINVAL,
+                 "greedy_advance: bad sizes");
+  if (num_seqs == 0) return MI355X_OK;
+  MI355X_REQUIRE(logits && tokens && positions && seq_lens && slot_mapping && block_tables, MI355X_EINVAL,
+                 "greedy_advance: null pointer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    hipLaunchKernelGGL(greedy_advance_kernel<scalar_t>, dim3(num_seqs), dim3(1024), 0, s,
+                       static_cast<const scalar_t*>(logits), logits_stride, vocab, tokens, positions,
+                       seq_lens, slot_mapping, block_tables, max_num_blocks_per_seq, block_size);
+    return check_launch("greedy_advance");
   });
 }

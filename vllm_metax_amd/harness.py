@@ -5,8 +5,8 @@ Stands in for the upstream-vLLM call stack that drives the reference's kernels
 attention / o_proj / RMSNorm / gate_up / SiluAndMul / down): the same sequence of ops, on
 synthetic weights of the named architecture (no checkpoints exist offline),
 with greedy sampling.  Every op on the hot path goes through the C-ABI
-(vllm_metax_amd._custom_ops); torch is used for allocation, the embedding gather, the
-un-quantised lm_head GEMM (library GEMM) and argmax.
+(vllm_metax_amd._custom_ops); torch is used for allocation, the embedding gather and the
+un-quantised lm_head GEMM (library GEMM).
 
 Decode steps are captured into a HIP graph (hipGraph via torch.cuda.CUDAGraph): all per-step
 index arithmetic (positions, slot mapping, sequence lengths) happens on the device inside
@@ -297,6 +297,9 @@ class HotPathModel:
         # at 8192 tokens (96 us vs 29.9 + 19.1 us: its V scatter is per token, reshape_and_cache's is a
         # 16-token tile transposed through LDS) -> off; bench 5585 vs 5639 tokens/s (profiles/r02 notes)
         self.fuse_prefill_rope = os.environ.get("MI355X_PREFILL_ROPE_FUSION", "0") != "0"
+        # greedy sampling + position / slot bookkeeping between two decode steps in one launch
+        # (mi355x_greedy_advance) instead of ~13 torch launches (~100 us per step); "0": the torch ops
+        self.fuse_greedy = os.environ.get("MI355X_FUSE_GREEDY", "1") != "0"
 
     # ---------------------------------------------------------------- helpers
     def _collectives(self) -> bool:
@@ -369,6 +372,9 @@ class HotPathModel:
         return out, residual, (None, 0)
 
     def _logits_argmax(self, x: torch.Tensor, residual: torch.Tensor, pending=(None, 0)) -> torch.Tensor:
+        return self._logits(x, residual, pending).argmax(dim=-1)
+
+    def _logits(self, x: torch.Tensor, residual: torch.Tensor, pending=(None, 0)) -> torch.Tensor:
         ops.fused_add_rms_norm_slabs(x, residual, self.final_norm, pending[0], pending[1], self.cfg.eps)
         logits = torch.matmul(x, self.lm_head)
         if self._collectives():
@@ -378,7 +384,7 @@ class HotPathModel:
             # [tp * M, V/tp] -> [M, V]: rank r owns vocabulary slice r
             logits = gathered.view(self.cfg.tp, logits.shape[0], logits.shape[1]).permute(1, 0, 2) \
                              .reshape(logits.shape[0], -1)
-        return logits.argmax(dim=-1)
+        return logits
 
     # ---------------------------------------------------------------- prefill
     def prefill(self, token_ids: torch.Tensor, seq_ids: List[int], context_len: int = 0):
@@ -417,6 +423,7 @@ class HotPathModel:
         self.d_seq_lens = torch.full((num_seqs,), start_len + 1, dtype=torch.int32, device=dev)
         self.d_seq_ids = torch.arange(num_seqs, dtype=torch.int64, device=dev)
         self.d_bt = self.block_tables[:num_seqs].contiguous()
+        self.d_slots = self._slots(self.d_seq_ids, self.d_positions)   # slot the next decode step writes
         self.d_max_seq_len = max_seq_len
         H = self.layers[0].q_heads
         P = (max_seq_len + ops.PARTITION_SIZE - 1) // ops.PARTITION_SIZE
@@ -429,9 +436,10 @@ class HotPathModel:
         """positions[s] = lengths[s] (index of the token being decoded), seq_lens = lengths + 1."""
         self.d_positions.copy_(lengths.to(torch.int64))
         self.d_seq_lens.copy_((lengths + 1).to(torch.int32))
+        self.d_slots.copy_(self._slots(self.d_seq_ids, self.d_positions))
 
     def _decode_body(self):
-        slots = self._slots(self.d_seq_ids, self.d_positions)
+        slots = self.d_slots
         x = self.embed[self.d_tokens]
         residual = None
 
@@ -447,10 +455,17 @@ class HotPathModel:
         for i in range(self.cfg.layers):
             x, residual, pending = self._layer(i, x, residual, self.d_positions, slots, attn_fn,
                                                pending, defer=True)
-        nxt = self._logits_argmax(x, residual, pending)
-        self.d_tokens.copy_(nxt)
-        self.d_positions.add_(1)
-        self.d_seq_lens.add_(1)
+        logits = self._logits(x, residual, pending)
+        if self.fuse_greedy:
+            # argmax + positions / seq_lens += 1 + the next step's slots: one launch instead of ~13 torch ones
+            ops.greedy_advance(logits.contiguous(), self.d_tokens, self.d_positions, self.d_seq_lens, self.d_slots,
+                               self.d_bt, self.BLOCK)
+        else:
+            self.d_tokens.copy_(logits.argmax(dim=-1))
+            self.d_positions.add_(1)
+            self.d_seq_lens.add_(1)
+            last = self.d_bt.shape[1] * self.BLOCK - 1      # (a full sequence has no next slot: clamped, unused)
+            self.d_slots.copy_(self._slots(self.d_seq_ids, self.d_positions.clamp(max=last)))
 
     def decode_step(self, use_graph: bool = True):
         """One decode step for all sequences.  With use_graph the step is replayed from a HIP graph
@@ -473,10 +488,11 @@ class HotPathModel:
             # warm up on a side stream (also initialises the communicator), then capture
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
-            saved = (self.d_tokens.clone(), self.d_positions.clone(), self.d_seq_lens.clone())
+            saved = (self.d_tokens.clone(), self.d_positions.clone(), self.d_seq_lens.clone(), self.d_slots.clone())
 
             def restore():
                 self.d_tokens.copy_(saved[0]); self.d_positions.copy_(saved[1]); self.d_seq_lens.copy_(saved[2])
+                self.d_slots.copy_(saved[3])
             with torch.cuda.stream(s):
                 self._decode_body()
             torch.cuda.current_stream().wait_stream(s)
