@@ -432,6 +432,21 @@ int mi355x_qkv_rope_cache(void* qkv, int64_t qkv_stride, const float* slabs, int
                           int64_t key_block_stride, int64_t value_block_stride, int dtype,
                           mi355x_stream stream);
 
+/* paged_attention_fused_qkv: qkv_rope_cache (above) folded into the decode attention launch that follows it:
+ * the workgroup of (sequence, kv head) builds its query heads, k head and v head of the new token from the
+ * qkv row (sk == 0) or its split-K slabs, applies the NeoX rotary to q and k, writes k / v into the cache slot
+ * and runs paged_attention_v1 (partition_size 0) or _v2 (partition_size 512 + the reduce launch) on q.
+ * Bit-identical to mi355x_qkv_rope_cache + mi355x_paged_attention_v1/_v2 (out and caches; the qkv buffer
+ * itself is NOT updated).  Applies to 2-byte dtypes, head_size 128, block_size 16, x 8, 4 query heads per
+ * kv head, scalar_t caches; otherwise returns 1 (no error): run the two calls instead. */
+int mi355x_paged_attention_fused_qkv(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* qkv, int64_t qkv_stride,
+    const float* slabs, int sk, const int64_t* positions, const void* cos_sin_cache,
+    const int64_t* slot_mapping, void* key_cache, void* value_cache, int num_seqs, int num_heads,
+    int num_kv_heads, int head_size, int block_size, int x, float scale, const int* block_tables,
+    const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len, int64_t kv_block_stride,
+    int64_t kv_head_stride, int partition_size, int dtype, mi355x_stream stream);
+
 /* greedy_advance: the bookkeeping between two greedy decode steps, one launch (the reference has no op
  * for it: upstream vLLM's sampler and model runner do it with torch ops — argmax, three in-place adds and
  * the block-table gather that yields slot_mapping; ~13 launches, ~100 us per step at vocab 128256):

@@ -112,3 +112,7 @@ def greedy_advance(logits, tokens, positions, seq_lens, slot_mapping, block_tabl
     bi = (positions // block_size).clamp(max=block_tables.shape[1] - 1)
     blk = block_tables[torch.arange(positions.numel()), bi].long()
     slot_mapping.copy_(blk * block_size + positions % block_size)
+
+
+def paged_attention_fused_qkv(*a, **k):
+    return False          # the CPU shim has no fused form: the harness falls back to qkv_rope_cache + attention

@@ -15,7 +15,7 @@ import random
 import pytest
 import torch
 
-from tests.util import assert_close_rel, dev, make_kv_cache_x
+from tests.util import assert_bit_exact, assert_close_rel, dev, make_kv_cache_x
 
 pytestmark = pytest.mark.gpu
 
@@ -285,3 +285,66 @@ def test_paged_attention_tp8_per_rank_heads():
         assert_close_rel(_run_v1(*args, 1, 16), ref1, 1e-3, "v1 8q/1kv", abs_floor=_tol(ref1))
         ref2 = R.paged_attention_v2(q, kc, vc, 1, scale, bt, sl, max_len, slopes)[0]
         assert_close_rel(_run_v2(*args, 1, 16)[0], ref2, 1e-3, "v2 8q/1kv", abs_floor=_tol(ref2))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("sk", [0, 3])
+@pytest.mark.parametrize("partitioned", [False, True])
+def test_fused_qkv_attention_is_bit_identical(dtype, sk, partitioned):
+    """mi355x_paged_attention_fused_qkv == qkv_rope_cache followed by paged_attention_v1 / _v2, bit for bit:
+    attention output and both caches (ragged lengths incl. a token that opens a new block, a sequence of one
+    token, a context that spans several 512-token partitions)."""
+    from vllm_metax_amd import _custom_ops as ops
+    H, KVH, D, BS = 8, 2, 128, 16
+    lens = [1, 16, 17, 33, 512, 513, 1100, 640]
+    n = len(lens)
+    g = torch.Generator().manual_seed(11 + sk)
+    max_len = max(lens)
+    nblk = (max_len + BS - 1) // BS
+    nb = n * nblk + 3
+    d = dev()
+    kc = (torch.randn(nb, KVH, D // 8, BS, 8, generator=g) * 0.5).to(dtype).to(d)
+    vc = (torch.randn(nb, KVH, D, BS, generator=g) * 0.5).to(dtype).to(d)
+    bt = torch.randperm(nb, generator=g)[:n * nblk].to(torch.int32).view(n, nblk).to(d)
+    sl = torch.tensor(lens, dtype=torch.int32, device=d)
+    pos = (sl - 1).to(torch.int64)
+    slots = (bt[torch.arange(n, device=d), (pos // BS)].long() * BS + pos % BS)
+    width = (H + 2 * KVH) * D
+    qkv = (torch.randn(n, width, generator=g) * 0.5).to(dtype).to(d)
+    slabs = (torch.randn(max(sk, 1), n, width, generator=g) * 0.3).to(d)
+    cos_sin = torch.randn(2048, D, generator=g).to(dtype).to(d)
+    scale = D ** -0.5
+    P = (max_len + ops.PARTITION_SIZE - 1) // ops.PARTITION_SIZE
+    es = torch.empty(n, H, P, dtype=torch.float32, device=d)
+    ml = torch.empty_like(es)
+    tmp = torch.empty(n, H, P, D, dtype=dtype, device=d)
+
+    def unfused():
+        q2, k2, v2 = qkv.clone(), kc.clone(), vc.clone()
+        ops.qkv_rope_cache(q2, slabs, sk, pos, cos_sin, k2, v2, slots, H, KVH, D)
+        out = torch.empty(n, H, D, dtype=dtype, device=d)
+        q3 = q2[:, :H * D].view(n, H, D)
+        if partitioned:
+            ops.paged_attention_v2(out, es, ml, tmp, q3, k2, v2, KVH, scale, bt, sl, BS, max_len, None)
+        else:
+            ops.paged_attention_v1(out, q3, k2, v2, KVH, scale, bt, sl, BS, max_len, None)
+        return out, k2, v2
+
+    ref_out, ref_k, ref_v = unfused()
+    k3, v3 = kc.clone(), vc.clone()
+    out = torch.empty(n, H, D, dtype=dtype, device=d)
+    ok = ops.paged_attention_fused_qkv(out, es, ml, tmp, qkv.clone(), slabs, sk, pos, cos_sin, slots, k3, v3,
+                                       H, KVH, scale, bt, sl, BS, max_len, partitioned)
+    assert ok
+    assert_bit_exact(k3, ref_k, "key cache")
+    assert_bit_exact(v3, ref_v, "value cache")
+    assert_bit_exact(out, ref_out, "attention output")
+    # not applicable (8 query heads per kv head -> two workgroups per kv head): reports False, launches nothing
+    k4 = kc.clone()
+    out10 = torch.empty(n, H + 2, D, dtype=dtype, device=d)
+    es10 = torch.empty(n, H + 2, P, dtype=torch.float32, device=d)
+    tmp10 = torch.empty(n, H + 2, P, D, dtype=dtype, device=d)
+    assert not ops.paged_attention_fused_qkv(out10, es10, es10.clone(), tmp10, qkv.clone(), slabs, sk, pos, cos_sin,
+                                             slots, k4[:, :1], v3[:, :1], H + 2, 1, scale, bt, sl, BS, max_len,
+                                             partitioned)
+    assert_bit_exact(k4, kc, "untouched")

@@ -689,6 +689,50 @@ def awq_gemm_silu_mul(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.
     return out
 
 
+def paged_attention_fused_qkv(out: torch.Tensor, exp_sums: Optional[torch.Tensor],
+                              max_logits: Optional[torch.Tensor], tmp_out: Optional[torch.Tensor],
+                              qkv: torch.Tensor, slabs: Optional[torch.Tensor], sk: int,
+                              positions: torch.Tensor, cos_sin_cache: torch.Tensor,
+                              slot_mapping: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                              num_heads: int, num_kv_heads: int, scale: float, block_tables: torch.Tensor,
+                              seq_lens: torch.Tensor, block_size: int, max_seq_len: int,
+                              partitioned: bool) -> bool:
+    """MI355X-side decode fusion: qkv_rope_cache folded into the paged-attention launch that follows it
+    (include/mi355x_hotpath.h).  Returns False when the fused form does not apply to these shapes — the
+    caller then runs qkv_rope_cache + paged_attention_v1 / _v2.  `out` [n, H, D]; the qkv buffer is not updated."""
+    _dev(out, qkv, positions, cos_sin_cache, slot_mapping, key_cache, value_cache, block_tables, seq_lens)
+    if qkv.dim() != 2 or qkv.stride(1) != 1 or key_cache.dim() != 5 or value_cache.dim() != 4:
+        raise RuntimeError("paged_attention_fused_qkv: qkv [tokens, width], caches in the x-split layout")
+    if positions.dtype != torch.int64 or slot_mapping.dtype != torch.int64:
+        raise RuntimeError("paged_attention_fused_qkv: positions and slot_mapping must be int64")
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("paged_attention_fused_qkv: block_tables and seq_lens must be int32")
+    head_size = key_cache.size(2) * key_cache.size(4)
+    if qkv.dtype not in (torch.bfloat16, torch.float16) or key_cache.dtype != qkv.dtype \
+            or cos_sin_cache.dtype != qkv.dtype or cos_sin_cache.size(-1) != head_size:
+        return False
+    n = qkv.size(0)
+    if not out.is_contiguous() or out.numel() != n * num_heads * head_size:
+        raise RuntimeError("paged_attention_fused_qkv: out must be contiguous [tokens, heads, head_size]")
+    if sk > 0:
+        _dev(slabs)
+        if slabs.dtype != torch.float32 or slabs.numel() < sk * n * qkv.size(1):
+            raise RuntimeError("paged_attention_fused_qkv: slabs must be float32 [sk, tokens, width]")
+    if partitioned:
+        _dev(exp_sums, max_logits, tmp_out)
+    rc = _abi.load().mi355x_paged_attention_fused_qkv(
+        _ptr(out), _ptr(exp_sums) if partitioned else None, _ptr(max_logits) if partitioned else None,
+        _ptr(tmp_out) if partitioned else None, _ptr(qkv), qkv.stride(0), _ptr(slabs) if sk > 0 else None,
+        int(sk), _ptr(positions), _ptr(cos_sin_cache), _ptr(slot_mapping), _ptr(key_cache), _ptr(value_cache),
+        n, num_heads, num_kv_heads, head_size, block_size, key_cache.size(4), float(scale), _ptr(block_tables),
+        _ptr(seq_lens), block_tables.stride(0), max_seq_len, key_cache.stride(0), key_cache.stride(1),
+        PARTITION_SIZE if partitioned else 0, _dt(qkv), _stream())
+    if rc == 1:
+        return False
+    _abi.check(rc, "paged_attention_fused_qkv")
+    return True
+
+
 def greedy_advance(logits: torch.Tensor, tokens: torch.Tensor, positions: torch.Tensor,
                    seq_lens: torch.Tensor, slot_mapping: torch.Tensor, block_tables: torch.Tensor,
                    block_size: int) -> None:

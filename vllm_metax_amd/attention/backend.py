@@ -206,6 +206,24 @@ def decode_attention(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torc
                                alibi_slopes, kv_cache_dtype, k_scale, v_scale)
 
 
+def decode_attention_fused(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torch.Tensor,
+                           tmp_out: torch.Tensor, qkv: torch.Tensor, slabs: Optional[torch.Tensor], sk: int,
+                           positions: torch.Tensor, cos_sin_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                           key_cache: torch.Tensor, value_cache: torch.Tensor, num_heads: int, num_kv_heads: int,
+                           scale: float, block_table: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
+                           max_seq_len: int, use_v1: Optional[bool] = None) -> bool:
+    """qkv_rope_cache + decode_attention in one launch (MI355X-side fusion, include/mi355x_hotpath.h), with the
+    same v1 / v2 choice as decode_attention.  False: not applicable to these shapes, nothing was launched."""
+    head_size = key_cache.shape[2] * key_cache.shape[4]
+    if use_v1 is None:
+        use_v1 = use_paged_attention_v1(qkv.shape[0], num_heads, max_seq_len, num_kv_heads, head_size,
+                                        block_size, qkv.dtype)
+    return ops.paged_attention_fused_qkv(out, exp_sums, max_logits, tmp_out, qkv, slabs, sk, positions,
+                                         cos_sin_cache, slot_mapping, key_cache, value_cache, num_heads,
+                                         num_kv_heads, scale, block_table, seq_lens, block_size, max_seq_len,
+                                         not use_v1)
+
+
 def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
                             value: Optional[torch.Tensor], kv_cache: torch.Tensor,
                             md: Mi355xPagedMetadata, output: torch.Tensor, num_kv_heads: int,

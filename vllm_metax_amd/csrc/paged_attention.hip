@@ -195,22 +195,41 @@ __device__ __forceinline__ uint4 mask_tail(uint4 v, int first_token, int seq_len
   return *reinterpret_cast<uint4*>(e);
 }
 
+// FQ (mi355x_paged_attention_fused_qkv): the decode step's "slab sum -> NeoX rotary -> reshape_and_cache" of
+// the new token happens in THIS kernel's prologue instead of a launch of its own (qkv_rope_cache_kernel, the
+// same arithmetic): the workgroup of (sequence, kv head) builds its GT query heads, its k head and its v head
+// from the qkv row (or its split-K slabs), rotates q and k, keeps q in LDS and writes k / v into the cache slot
+// of the new token, which its own QK^T / PV loops then read back (same workgroup: a release fence + barrier
+// orders the stores before the loads; no other workgroup reads that kv head of that sequence).
+struct FusedQkv {
+  const void* qkv;            // [num_seqs, qkv_stride] scalar_t rows q | k | v (read when sk == 0)
+  int64_t qkv_stride;
+  const float* slabs;         // [sk][num_seqs][width] fp32 split-K partials of the qkv projection, or null
+  int sk;
+  int64_t slab_stride;
+  const int64_t* positions;   // [num_seqs]
+  const void* cos_sin_cache;  // [max_pos, head_size] scalar_t
+  const int64_t* slot_mapping;  // [num_seqs]
+};
+
 // HS == 0: head size is a run-time value (any multiple of 16/sizeof(T) up to 256).
 // CT: element type of the cache (T, or uint8_t = e4m3fn bytes with x = 16).
-template <typename T, typename CT, int BS, int GT, int HS>
+template <typename T, typename CT, int BS, int GT, int HS, bool FQ = false>
 __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
     float* __restrict__ exp_sums,    // [num_seqs, num_heads, P]       (partitioned only)
     float* __restrict__ max_logits,  // [num_seqs, num_heads, P]       (partitioned only)
     T* __restrict__ out,             // [num_seqs, num_heads, P, head_size]
     const T* __restrict__ q,         // [num_seqs, num_heads, head_size]
-    const CT* __restrict__ k_cache,  // [num_blocks, num_kv_heads, head_size/x, BS, x]
-    const CT* __restrict__ v_cache,  // [num_blocks, num_kv_heads, head_size, BS]
+    // (FQ: the kernel writes the caches too — no __restrict__ promise on them)
+    typename std::conditional<FQ, const CT*, const CT* __restrict__>::type k_cache,  // [num_blocks, num_kv_heads, head_size/x, BS, x]
+    typename std::conditional<FQ, const CT*, const CT* __restrict__>::type v_cache,  // [num_blocks, num_kv_heads, head_size, BS]
     int num_heads, int num_kv_heads, int head_size_rt, float scale,
     const int* __restrict__ block_tables, const int* __restrict__ seq_lens,
     int max_num_blocks_per_seq, const float* __restrict__ alibi_slopes, int64_t q_stride,
     int64_t kv_block_stride, int64_t kv_head_stride, int partition_size, int logits_cap,
-    const float* __restrict__ k_scale, const float* __restrict__ v_scale) {
+    const float* __restrict__ k_scale, const float* __restrict__ v_scale, FusedQkv fq = FusedQkv{}) {
   constexpr bool KV8 = !std::is_same<T, CT>::value;
+  static_assert(!FQ || (!KV8 && HS != 0 && sizeof(T) == 2), "fused qkv: 2-byte scalar_t cache, fixed head size");
   constexpr int XT = 16 / sizeof(T);           // scalar_t elements per 16 B (q staging)
   constexpr int X = 16 / sizeof(CT);           // cache elements per 16-B piece
   constexpr int QP = Piece<T, CT>::QP;         // uint4s of scalar_t that one piece expands to
@@ -263,6 +282,63 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   // global load in front of every K / V block
   int* bt_s = reinterpret_cast<int*>(probs + (size_t)GT * logits_cap);  // [cap / BS]
 
+  // physical block ids of the partition first: their latency overlaps with the q staging / prologue below
+  const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+  for (int i = tid; i < end_block - start_block; i += nthreads) bt_s[i] = block_table[start_block + i];
+  if constexpr (FQ) {
+    // ---- q | k | v of the new token: [slab sum ->] T, rotary on q and k, k / v into the cache ----
+    // (host: tiles == 1 and nheads == GT; rows of q_s: GT query heads, then the k head, then the v head)
+    const int width = (num_heads + 2 * num_kv_heads) * D;
+    // position, slot and this thread's cos / sin chunk are requested up front, with the slab loads: behind
+    // them they would be two more dependent memory round trips in front of the first K load
+    const int embed = D / 2;
+    const int cph = embed / XT;
+    const int64_t slot = fq.slot_mapping[seq];
+    const T* cos_ptr = static_cast<const T*>(fq.cos_sin_cache) + fq.positions[seq] * D;
+    Vec16<T> cs0, sn0;
+    if (tid < (GT + 1) * cph) {
+      cs0 = load16(cos_ptr + (tid % cph) * XT);
+      sn0 = load16(cos_ptr + embed + (tid % cph) * XT);
+    }
+    for (int i = tid; i < (GT + 2) * CQ; i += nthreads) {
+      const int hs = i / CQ;
+      const int c = i - hs * CQ;
+      const int col = (hs < GT ? head0 + hs : (hs == GT ? num_heads + kv_head : num_heads + num_kv_heads + kv_head)) * D + c * XT;
+      Vec16<T> v;
+      if (fq.sk > 0) {
+        float acc[XT];
+        sum_slabs<XT>(fq.slabs + (int64_t)seq * width + col, fq.sk, fq.slab_stride, acc);
+#pragma unroll
+        for (int j = 0; j < XT; ++j) v.e[j] = from_f32<T>(acc[j]);
+      } else {
+        v = load16(static_cast<const T*>(fq.qkv) + (int64_t)seq * fq.qkv_stride + col);
+      }
+      store16(q_s + hs * D + c * XT, v);
+    }
+    __syncthreads();
+    if (tid < (GT + 1) * cph) {     // (GT + 1) * cph <= 40 <= the workgroup size: one chunk pair per thread
+      const int h = tid / cph;
+      const int c = tid - h * cph;
+      T* base = q_s + h * D;
+      Vec16<T> x = load16(base + c * XT);
+      Vec16<T> y = load16(base + embed + c * XT);
+#pragma unroll
+      for (int j = 0; j < XT; ++j) rot_pair<T>(x.e[j], y.e[j], cs0.e[j], sn0.e[j]);
+      store16(base + c * XT, x);
+      store16(base + embed + c * XT, y);
+    }
+    __syncthreads();
+    // the workgroup whose token range ends with the new token (v1: the only one) writes it
+    if (slot >= 0 && (!partitioned || part == (seq_len - 1) / partition_size)) {
+      const int64_t blk = slot / BS;
+      const int t = (int)(slot - blk * BS);
+      T* kw = const_cast<T*>(reinterpret_cast<const T*>(k_cache)) + blk * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+      T* vw = const_cast<T*>(reinterpret_cast<const T*>(v_cache)) + blk * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+      for (int c = tid; c < CQ; c += nthreads) store16(kw + (c * BS + t) * XT, load16(q_s + GT * D + c * XT));
+      for (int d = tid; d < D; d += nthreads) vw[(int64_t)d * BS + t] = q_s[(GT + 1) * D + d];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are complete before the barrier below
+  } else {
   // ---- stage q (packed scalar_t) into LDS; absent heads are zero ---------------
   for (int i = tid; i < GT * CQ; i += nthreads) {
     const int g = i / CQ;
@@ -273,9 +349,9 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
     }
     *reinterpret_cast<uint4*>(q_s + g * D + c * XT) = v;
   }
-  const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
-  for (int i = tid; i < end_block - start_block; i += nthreads) bt_s[i] = block_table[start_block + i];
+  }
   __syncthreads();
+  if constexpr (FQ) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
   float slope[GT];
 #pragma unroll
@@ -606,6 +682,7 @@ struct PaArgs {
   int kv_cache_dtype = MI355X_KV_AUTO;
   const float* k_scale = nullptr;
   const float* v_scale = nullptr;
+  const FusedQkv* fused = nullptr;   // mi355x_paged_attention_fused_qkv
 };
 
 // Launch geometry shared by the launcher and mi355x_paged_attention_v1_max_seq_len.
@@ -639,10 +716,10 @@ static PaPlan pa_plan(int num_seqs, int num_heads, int num_kv_heads, int head_si
   return p;
 }
 
-template <typename T, typename CT, int BS, int GT, int HS>
+template <typename T, typename CT, int BS, int GT, int HS, bool FQ = false>
 static int launch_pa_inst(const PaArgs& a, int tiles, int num_parts, int logits_cap,
                           size_t smem, int threads) {
-  auto kern = paged_attention_kernel<T, CT, BS, GT, HS>;
+  auto kern = paged_attention_kernel<T, CT, BS, GT, HS, FQ>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -658,7 +735,8 @@ static int launch_pa_inst(const PaArgs& a, int tiles, int num_parts, int logits_
                      static_cast<const CT*>(a.value_cache), a.num_heads, a.num_kv_heads,
                      a.head_size, a.scale, a.block_tables, a.seq_lens,
                      a.max_num_blocks_per_seq, a.alibi_slopes, a.q_stride, a.kv_block_stride,
-                     a.kv_head_stride, a.partition_size, logits_cap, a.k_scale, a.v_scale);
+                     a.kv_head_stride, a.partition_size, logits_cap, a.k_scale, a.v_scale,
+                     FQ ? *a.fused : FusedQkv{});
   return check_launch("paged_attention");
 }
 
@@ -671,6 +749,14 @@ static int launch_pa_bs(const PaArgs& a) {
                  "paged_attention_v2 (mi355x_paged_attention_v1_max_seq_len gives the limit)",
                  a.max_seq_len, p.smem);
   const bool fast = (a.head_size == 128) && (BS == 16) && (sizeof(T) == 2);
+  if (a.fused != nullptr) {
+    // fused qkv prologue: the shapes of the decode fast path with ONE workgroup per (sequence, kv head)
+    if constexpr (BS == 16 && sizeof(T) == 2 && std::is_same<T, CT>::value) {
+      if (fast && p.gt == 4 && p.tiles == 1 && a.num_heads / a.num_kv_heads == 4)
+        return launch_pa_inst<T, CT, BS, 4, 128, true>(a, p.tiles, p.num_parts, p.logits_cap, p.smem, p.threads);
+    }
+    return 1;   // not applicable: the caller runs qkv_rope_cache + paged_attention
+  }
 #define PA_CASE(GTV)                                                                            \
   if (p.gt == GTV) {                                                                            \
     if (fast) {                                                                                 \
@@ -745,6 +831,58 @@ static int validate_pa(const PaArgs& a, const char* name) {
 using namespace mi355x;
 
 extern "C" {
+
+// returns 1 (no error set) when the fused form does not apply to the shapes: the caller then runs
+// mi355x_qkv_rope_cache followed by mi355x_paged_attention_v1 / _v2
+int mi355x_paged_attention_fused_qkv(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* qkv, int64_t qkv_stride,
+    const float* slabs, int sk, const int64_t* positions, const void* cos_sin_cache,
+    const int64_t* slot_mapping, void* key_cache, void* value_cache, int num_seqs, int num_heads,
+    int num_kv_heads, int head_size, int block_size, int x, float scale, const int* block_tables,
+    const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len, int64_t kv_block_stride,
+    int64_t kv_head_stride, int partition_size, int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(sk >= 0 && partition_size >= 0, MI355X_EINVAL, "paged_attention_fused_qkv: bad sizes");
+  if (dtype != MI355X_BF16 && dtype != MI355X_F16) return 1;
+  if (head_size != 128 || block_size != 16 || x != 8) return 1;
+  PaArgs a{};
+  a.out = out; a.exp_sums = exp_sums; a.max_logits = max_logits; a.tmp_out = tmp_out;
+  a.query = qkv;   // (unused by the fused kernel; non-null for validate_pa)
+  a.key_cache = key_cache; a.value_cache = value_cache;
+  a.num_seqs = num_seqs; a.num_heads = num_heads; a.num_kv_heads = num_kv_heads;
+  a.head_size = head_size; a.block_size = block_size; a.scale = scale;
+  a.block_tables = block_tables; a.seq_lens = seq_lens;
+  a.max_num_blocks_per_seq = max_num_blocks_per_seq; a.max_seq_len = max_seq_len;
+  a.alibi_slopes = nullptr; a.q_stride = qkv_stride;
+  a.kv_block_stride = kv_block_stride; a.kv_head_stride = kv_head_stride;
+  a.partition_size = partition_size; a.stream = static_cast<hipStream_t>(stream);
+  int rc = validate_pa(a, "paged_attention_fused_qkv");
+  if (rc != MI355X_OK || num_seqs == 0) return rc;
+  MI355X_REQUIRE(positions && cos_sin_cache && slot_mapping && (sk == 0 || slabs), MI355X_EINVAL,
+                 "paged_attention_fused_qkv: null pointer");
+  MI355X_REQUIRE(partition_size == 0 || (exp_sums && max_logits && tmp_out), MI355X_EINVAL,
+                 "paged_attention_fused_qkv: the partitioned form needs exp_sums / max_logits / tmp_out");
+  MI355X_REQUIRE(partition_size == 0 || partition_size == MI355X_PA_PARTITION_SIZE, MI355X_EINVAL,
+                 "paged_attention_fused_qkv: partition_size must be 0 or %d", MI355X_PA_PARTITION_SIZE);
+  MI355X_REQUIRE(((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(slabs) |
+                   reinterpret_cast<uintptr_t>(cos_sin_cache) | reinterpret_cast<uintptr_t>(key_cache)) & 15) == 0 &&
+                     qkv_stride % 8 == 0,
+                 MI355X_EINVAL, "paged_attention_fused_qkv: 16-byte aligned qkv / slabs / cos_sin / cache");
+  FusedQkv f{qkv, qkv_stride, sk > 0 ? slabs : nullptr, sk,
+             (int64_t)num_seqs * (num_heads + 2 * num_kv_heads) * head_size, positions, cos_sin_cache, slot_mapping};
+  a.fused = &f;
+  rc = dtype == MI355X_BF16 ? launch_pa<bf16_t>(a) : launch_pa<f16_t>(a);
+  if (rc != MI355X_OK || partition_size == 0) return rc;
+  // partitioned: the same reduce as paged_attention_v2
+  const int max_parts = (max_seq_len + MI355X_PA_PARTITION_SIZE - 1) / MI355X_PA_PARTITION_SIZE;
+  return MI355X_DISPATCH_HALF(dtype, [&] {
+    hipLaunchKernelGGL(paged_attention_reduce_kernel<scalar_t>, dim3(num_heads, num_seqs),
+                       dim3(128), (size_t)(max_parts > 0 ? max_parts : 1) * sizeof(float), a.stream,
+                       static_cast<scalar_t*>(out), exp_sums, max_logits,
+                       static_cast<const scalar_t*>(tmp_out), seq_lens, head_size, max_parts,
+                       MI355X_PA_PARTITION_SIZE);
+    return check_launch("paged_attention_fused_qkv_reduce");
+  });
+}
 
 int mi355x_paged_attention_v1_max_seq_len(int num_seqs, int num_heads, int num_kv_heads,
                                           int head_size, int block_size, int dtype) {

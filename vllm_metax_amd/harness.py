@@ -22,7 +22,7 @@ from typing import List, Optional
 import torch
 
 from . import _custom_ops as ops
-from .attention.backend import decode_attention
+from .attention.backend import decode_attention, decode_attention_fused
 
 
 @dataclasses.dataclass
@@ -300,6 +300,9 @@ class HotPathModel:
         # greedy sampling + position / slot bookkeeping between two decode steps in one launch
         # (mi355x_greedy_advance) instead of ~13 torch launches (~100 us per step); "0": the torch ops
         self.fuse_greedy = os.environ.get("MI355X_FUSE_GREEDY", "1") != "0"
+        # decode: slab sum + rotary + cache write of the new token inside the attention launch
+        # (mi355x_paged_attention_fused_qkv) instead of a qkv_rope_cache launch in front of it; "0": two launches
+        self.fuse_attn_qkv = os.environ.get("MI355X_FUSE_ATTN_QKV", "1") != "0"
 
     # ---------------------------------------------------------------- helpers
     def _collectives(self) -> bool:
@@ -318,7 +321,7 @@ class HotPathModel:
 
     def _layer(self, i: int, x: torch.Tensor, residual: Optional[torch.Tensor],
                positions: torch.Tensor, slots: torch.Tensor, attn_fn, pending=(None, 0),
-               defer: bool = False):
+               defer: bool = False, attn_fused_fn=None):
         """`pending` = (slabs, sk) when x is still the unreduced output of the previous layer's
         down_proj (tp == 1 decode): the fused norm adds the slabs itself."""
         L = self.layers[i]
@@ -331,12 +334,15 @@ class HotPathModel:
         else:
             ops.fused_add_rms_norm_slabs(x, residual, L.ln1, pending[0], pending[1], cfg.eps)
             h = x
+        attn = None
         if defer and x.dtype != torch.float32 and self.kv_dtype == "auto":
             # decode: slab sum + rotary + cache write in one launch (column-parallel GEMM: no
             # collective between it and the rotary, so the fusion also holds under tp)
             qkv, slabs, sk = L.qkv.deferred(h)
-            ops.qkv_rope_cache(qkv, slabs, sk, positions, self.cos_sin, self.k_cache[i],
-                               self.v_cache[i], slots, L.q_heads, L.kv_heads, cfg.head_dim)
+            attn = attn_fused_fn(i, qkv, slabs, sk) if attn_fused_fn is not None else None
+            if attn is None:
+                ops.qkv_rope_cache(qkv, slabs, sk, positions, self.cos_sin, self.k_cache[i],
+                                   self.v_cache[i], slots, L.q_heads, L.kv_heads, cfg.head_dim)
             q = qkv[:, :L.q_size]
         elif self.fuse_prefill_rope and x.dtype != torch.float32 and self.kv_dtype == "auto":
             # prefill: rotary + cache write in one launch as well (the decode kernel, no slabs)
@@ -353,7 +359,8 @@ class HotPathModel:
             ops.reshape_and_cache(k.view(-1, L.kv_heads, cfg.head_dim), v.view(-1, L.kv_heads, cfg.head_dim),
                                   self.k_cache[i], self.v_cache[i], slots, self.kv_dtype, self.k_scale,
                                   self.v_scale)
-        attn = attn_fn(i, q.view(-1, L.q_heads, cfg.head_dim))
+        if attn is None:
+            attn = attn_fn(i, q.view(-1, L.q_heads, cfg.head_dim))
         if fuse:
             o, slabs, sk = L.o.deferred(attn.view(-1, L.q_size))
             ops.fused_add_rms_norm_slabs(o, residual, L.ln2, slabs, sk, cfg.eps)
@@ -451,10 +458,20 @@ class HotPathModel:
                              self.k_scale, self.v_scale)
             return out
 
+        def attn_fused_fn(i, qkv, slabs, sk):
+            L = self.layers[i]
+            out = torch.empty(qkv.shape[0], L.q_heads, self.cfg.head_dim, dtype=qkv.dtype, device=qkv.device)
+            ok = decode_attention_fused(out, self.d_es, self.d_ml, self.d_tmp, qkv, slabs, sk, self.d_positions,
+                                        self.cos_sin, slots, self.k_cache[i], self.v_cache[i], L.q_heads,
+                                        L.kv_heads, self.scale, self.d_bt, self.d_seq_lens, self.BLOCK,
+                                        self.d_max_seq_len)
+            return out if ok else None
+
         pending = (None, 0)
         for i in range(self.cfg.layers):
             x, residual, pending = self._layer(i, x, residual, self.d_positions, slots, attn_fn,
-                                               pending, defer=True)
+                                               pending, defer=True,
+                                               attn_fused_fn=attn_fused_fn if self.fuse_attn_qkv else None)
         logits = self._logits(x, residual, pending)
         if self.fuse_greedy:
             # argmax + positions / seq_lens += 1 + the next step's slots: one launch instead of ~13 torch ones
