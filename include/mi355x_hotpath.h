@@ -432,6 +432,20 @@ int mi355x_qkv_rope_cache(void* qkv, int64_t qkv_stride, const float* slabs, int
                           int64_t key_block_stride, int64_t value_block_stride, int dtype,
                           mi355x_stream stream);
 
+/* rms_norm_image / fused_add_rms_norm_image: rms_norm (fused_add_rms_norm) whose normalised output is written
+ * directly as the activation operand image of the prefill GEMM (the format mi355x_awq_gemm_silu_mul_packed
+ * produces and mi355x_w4a16_gemm_prepacked / mi355x_awq_gemm_packed_a consume: [row tile of 16][k tile of 32]
+ * [64 slots of 8 elements], rows >= num_tokens of the last tile zero), saving the re-tiling launch in front of
+ * the qkv / gate_up GEMMs of a prefill chunk.  `input` is NOT modified; fused: residual += input (rounded, as
+ * fused_add_rms_norm) in place.  Bit-identical to the row-major ops followed by the re-tiling.  2-byte dtypes,
+ * hidden_size 2048 or 4096, num_tokens >= 256; otherwise returns 1 (no error): run the row-major op.
+ * image: (roundup(num_tokens, 16) * hidden_size) elements, 16-byte aligned. */
+int mi355x_rms_norm_image(void* image, const void* input, const void* weight, float epsilon, int num_tokens,
+                          int hidden_size, int64_t input_stride, int dtype, mi355x_stream stream);
+int mi355x_fused_add_rms_norm_image(void* image, const void* input, void* residual, const void* weight,
+                                    float epsilon, int num_tokens, int hidden_size, int64_t input_stride,
+                                    int dtype, mi355x_stream stream);
+
 /* paged_attention_fused_qkv: qkv_rope_cache (above) folded into the decode attention launch that follows it:
  * the workgroup of (sequence, kv head) builds its query heads, k head and v head of the new token from the
  * qkv row (sk == 0) or its split-K slabs, applies the NeoX rotary to q and k, writes k / v into the cache slot

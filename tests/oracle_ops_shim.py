@@ -116,3 +116,11 @@ def greedy_advance(logits, tokens, positions, seq_lens, slot_mapping, block_tabl
 
 def paged_attention_fused_qkv(*a, **k):
     return False          # the CPU shim has no fused form: the harness falls back to qkv_rope_cache + attention
+
+
+def rms_norm_image(x, weight, eps):
+    return None           # no image form on the CPU shim: the harness runs the row-major op
+
+
+def fused_add_rms_norm_image(x, residual, weight, eps):
+    return None

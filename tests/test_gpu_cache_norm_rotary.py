@@ -491,3 +491,50 @@ def test_greedy_advance(dtype, n, vocab):
     tok2 = torch.zeros_like(tok)
     ops().greedy_advance(wide[:, :vocab], tok2, posd, seqd, slots, btd, bs)
     assert torch.equal(tok2.cpu(), ref_tok)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,hidden", [(1024, 4096), (1300, 4096), (300, 2048), (8192, 4096)])
+@pytest.mark.parametrize("fused", [False, True])
+def test_rms_norm_image_is_bit_identical(dtype, m, hidden, fused):
+    """MI355X-side prefill fusion: (fused_add_)rms_norm written as the prefill GEMM's operand image == the
+    row-major op followed by the re-tiling, bit for bit (image layout: [row tile 16][k tile 32][64 slots of
+    8 elements], slot lr * 16 + (lc ^ g(lr)) = A[16 mt + lc][32 kt + 8 lr ..], rows past the end zero)."""
+    g = torch.Generator().manual_seed(m + hidden)
+    d = dev()
+    x = (torch.randn(m, hidden + 8, generator=g) * 2).to(dtype).to(d)[:, :hidden]     # strided rows
+    res = torch.randn(m, hidden, generator=g).to(dtype).to(d)
+    w = torch.randn(hidden, generator=g).to(dtype).to(d)
+    if fused:
+        x_ref, r_ref = x.clone(), res.clone()
+        ops().fused_add_rms_norm(x_ref, r_ref, w, 1e-5)
+        r2 = res.clone()
+        img = ops().fused_add_rms_norm_image(x, r2, w, 1e-5)
+        assert_bit_exact(r2, r_ref, "residual")
+        ref = x_ref
+    else:
+        ref = torch.empty(m, hidden, dtype=dtype, device=d)
+        ops().rms_norm(ref, x, w, 1e-5)
+        img = ops().rms_norm_image(x, w, 1e-5)
+    assert img is not None and img.shape == (m, hidden)
+    mt, kt = (m + 15) // 16, hidden // 32
+    pad = torch.zeros(mt * 16, hidden, dtype=dtype, device=d)
+    pad[:m] = ref
+    # expected image: piece (mt, kt) slot s holds row 16 mt + lc, k 32 kt + 8 lr .. +7 with s = lr*16 + (lc ^ g(lr))
+    t = pad.view(mt, 16, kt, 4, 8)                        # [mt, lc, kt, lr, 8]
+    exp = torch.empty(mt, kt, 64, 8, dtype=dtype, device=d)
+    for lr in range(4):
+        gx = ((lr & 1) * 12) | (lr & 2)
+        for lc in range(16):
+            exp[:, :, lr * 16 + (lc ^ gx)] = t[:, lc, :, lr]
+    assert_bit_exact(img.data.view(mt, kt, 64, 8), exp, "operand image")
+
+
+def test_norm_image_not_applicable_returns_none():
+    d = dev()
+    x = torch.randn(64, 4096, device=d).to(torch.bfloat16)
+    w = torch.ones(4096, device=d, dtype=torch.bfloat16)
+    assert ops().rms_norm_image(x, w, 1e-5) is None                 # decode-sized batch
+    x2 = torch.randn(1024, 1024, device=d).to(torch.bfloat16)
+    assert ops().rms_norm_image(x2, torch.ones(1024, device=d, dtype=torch.bfloat16), 1e-5) is None
+    assert ops().rms_norm_image(x.float().repeat(16, 1), w.float(), 1e-5) is None

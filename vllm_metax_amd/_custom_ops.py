@@ -689,6 +689,40 @@ def awq_gemm_silu_mul(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.
     return out
 
 
+def _norm_image(name: str, x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor,
+                epsilon: float) -> Optional["PackedOperand"]:
+    _dev(x, residual, weight)
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (torch.bfloat16, torch.float16):
+        return None
+    m, hidden = x.shape
+    if residual is not None and (not residual.is_contiguous() or residual.shape != x.shape):
+        raise RuntimeError(f"{name}: residual must be contiguous and shaped like the input")
+    image = torch.empty(((m + 15) // 16) * 16 * hidden, dtype=x.dtype, device=x.device)
+    lib = _abi.load()
+    if residual is None:
+        rc = lib.mi355x_rms_norm_image(_ptr(image), _ptr(x), _ptr(weight), float(epsilon), m, hidden,
+                                       x.stride(0), _dt(x), _stream())
+    else:
+        rc = lib.mi355x_fused_add_rms_norm_image(_ptr(image), _ptr(x), _ptr(residual), _ptr(weight),
+                                                 float(epsilon), m, hidden, x.stride(0), _dt(x), _stream())
+    if rc == 1:
+        return None
+    _abi.check(rc, name)
+    return PackedOperand(image, m, hidden)
+
+
+def rms_norm_image(x: torch.Tensor, weight: torch.Tensor, epsilon: float) -> Optional["PackedOperand"]:
+    """MI355X-side prefill fusion: rms_norm(x) written directly as the prefill GEMM's activation operand
+    image (None: not applicable to these shapes; bit-identical to rms_norm + the GEMM's own re-tiling)."""
+    return _norm_image("rms_norm_image", x, None, weight, epsilon)
+
+
+def fused_add_rms_norm_image(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                             epsilon: float) -> Optional["PackedOperand"]:
+    """Like rms_norm_image for fused_add_rms_norm: residual += x in place (rounded), x itself is not modified."""
+    return _norm_image("fused_add_rms_norm_image", x, residual, weight, epsilon)
+
+
 def paged_attention_fused_qkv(out: torch.Tensor, exp_sums: Optional[torch.Tensor],
                               max_logits: Optional[torch.Tensor], tmp_out: Optional[torch.Tensor],
                               qkv: torch.Tensor, slabs: Optional[torch.Tensor], sk: int,

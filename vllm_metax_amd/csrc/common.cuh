@@ -90,6 +90,14 @@ template <typename T>
 __device__ __forceinline__ float to_f32(T v) {
   return static_cast<float>(v);
 }
+// from_f32 of a value the compiler must MATERIALISE in fp32 first: for T = f16, hipcc folds
+// T(float(a_f16) * b_f32) into v_fma_mixlo_f16, which rounds the exact product ONCE to f16, while the reference
+// (fp32 multiply, then the scalar_t cast) rounds twice — about one output in 8000 differs by an ulp.
+template <typename T>
+__device__ __forceinline__ T from_f32_rounded(float v) {
+  asm volatile("" : "+v"(v));
+  return static_cast<T>(v);
+}
 // Round-to-nearest-even conversions (c10::BFloat16 / c10::Half semantics).
 template <typename T>
 __device__ __forceinline__ T from_f32(float v) {

@@ -105,7 +105,7 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
     if (idx < hidden_size) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
-        const T n = from_f32<T>(x[c][j] * inv_rms);
+        const T n = from_f32_rounded<T>(x[c][j] * inv_rms);
         const T o = mul_t<T>(n, wreg[c][j]);
         x[c][j] = to_f32(o);
         amax = fmaxf(amax, fabsf(x[c][j]));
@@ -206,6 +206,102 @@ static int launch_norm(void* out, T* input, int64_t input_stride, T* residual,
   return check_launch(name);
 }
 
+// ---- rms_norm / fused_add_rms_norm whose output is the prefill GEMM's operand image ----------------
+// (mi355x_rms_norm_image: saves the activation re-tiling launch, pack_a_kernel, in front of the qkv and
+// gate_up GEMMs of a prefill chunk.)  One workgroup = one 16-row tile of the image, one wave per row, so the
+// 16-byte slots a workgroup writes complete whole 1-KiB pieces inside one XCD's L2.
+// Bit-identical to rms_norm_kernel<T, 8, MAXC, ..> at 256 threads (what launch_norm picks for >= 256 tokens):
+// lane l replays the partial sums of that kernel's threads l, l + 64, l + 128, l + 192 (chunks t + 256 c in
+// the same order), the four wave sums use the same butterfly, and block_reduce's lane tree adds them as
+// (W0 + W2) + (W1 + W3).
+__device__ __forceinline__ int norm_frag_swz(int lr, int lc) {   // = frag_swz of w4a16.cuh (operand image slot)
+  return lr * 16 + (lc ^ (((lr & 1) * 12) | (lr & 2)));
+}
+template <typename T, int MAXC, bool FUSED_ADD>
+__global__ __launch_bounds__(1024) void rms_norm_image_kernel(
+    T* __restrict__ image, const T* __restrict__ input, int64_t input_stride, T* __restrict__ residual,
+    const T* __restrict__ weight, float epsilon, int num_tokens, int hidden_size) {
+  constexpr int V = 8;
+  const int lane = threadIdx.x & 63;
+  const int lc = threadIdx.x >> 6;                      // row of the tile = wave
+  const int64_t row = (int64_t)blockIdx.x * 16 + lc;
+  const bool live = row < num_tokens;
+  const T* in_row = input + row * input_stride;
+  T* res_row = residual + row * hidden_size;
+  float x[4][MAXC][V];
+  T wreg[4][MAXC][V];
+  float part[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int idx = (c * 256 + 64 * k + lane) * V;
+      T iv[V], rv[V];
+      if (live) {
+        *reinterpret_cast<uint4*>(iv) = *reinterpret_cast<const uint4*>(in_row + idx);
+        if constexpr (FUSED_ADD) *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res_row + idx);
+      } else {
+        *reinterpret_cast<uint4*>(iv) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(rv) = make_uint4(0, 0, 0, 0);
+      }
+      *reinterpret_cast<uint4*>(wreg[k][c]) = *reinterpret_cast<const uint4*>(weight + idx);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float v = to_f32(iv[j]);
+        if constexpr (FUSED_ADD) {
+          v += to_f32(rv[j]);
+          const T z = from_f32<T>(v);
+          rv[j] = z;
+          v = to_f32(z);  // norm of the ROUNDED sum
+        }
+        x[k][c][j] = v;
+        ss += v * v;
+      }
+      if constexpr (FUSED_ADD) {
+        if (live) *reinterpret_cast<uint4*>(res_row + idx) = *reinterpret_cast<const uint4*>(rv);
+      }
+    }
+    part[k] = wave_sum(ss);
+  }
+  const float ss = (part[0] + part[2]) + (part[1] + part[3]);
+  const float inv_rms = rsqrtf(ss / hidden_size + epsilon);
+  const int kt32 = hidden_size >> 5;
+  uint4* img = reinterpret_cast<uint4*>(image) + (int64_t)blockIdx.x * kt32 * 64;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int ch = c * 256 + 64 * k + lane;            // 16-byte chunk of the row
+      T ov[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const T n = from_f32_rounded<T>(x[k][c][j] * inv_rms);
+        ov[j] = live ? mul_t<T>(n, wreg[k][c][j]) : from_f32<T>(0.f);   // rows >= num_tokens of the tile: zero
+      }
+      img[(ch >> 2) * 64 + norm_frag_swz(ch & 3, lc)] = *reinterpret_cast<const uint4*>(ov);
+    }
+  }
+}
+
+// returns 1 when the image form does not apply (caller: rms_norm / fused_add_rms_norm + the GEMM's own re-tiling)
+template <typename T, bool FUSED_ADD>
+static int launch_norm_image(T* image, const T* input, int64_t input_stride, T* residual, const T* weight,
+                             float eps, int num_tokens, int hidden, hipStream_t s, const char* name) {
+  if (num_tokens < 256 || (hidden != 2048 && hidden != 4096) || input_stride % 8 != 0 || !al16(input) ||
+      !al16(weight) || !al16(image) || (FUSED_ADD && !al16(residual)))
+    return 1;
+  dim3 grid((num_tokens + 15) / 16), block(1024);
+  if (hidden == 2048) {
+    hipLaunchKernelGGL((rms_norm_image_kernel<T, 1, FUSED_ADD>), grid, block, 0, s, image, input, input_stride,
+                       residual, weight, eps, num_tokens, hidden);
+  } else {
+    hipLaunchKernelGGL((rms_norm_image_kernel<T, 2, FUSED_ADD>), grid, block, 0, s, image, input, input_stride,
+                       residual, weight, eps, num_tokens, hidden);
+  }
+  return check_launch(name);
+}
+
 }  // namespace mi355x
 
 using namespace mi355x;
@@ -260,6 +356,35 @@ int mi355x_fused_add_rms_norm_slabs(void* input, void* residual, const void* wei
         static_cast<const scalar_t*>(weight), nullptr, nullptr, nullptr, epsilon, num_tokens,
         hidden_size, static_cast<hipStream_t>(stream), "fused_add_rms_norm_slabs",
         sk > 0 ? slabs : nullptr, sk, (int64_t)num_tokens * hidden_size);
+  });
+}
+
+int mi355x_rms_norm_image(void* image, const void* input, const void* weight, float epsilon, int num_tokens,
+                          int hidden_size, int64_t input_stride, int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && hidden_size > 0, MI355X_EINVAL, "rms_norm_image: bad sizes");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(image && input && weight, MI355X_EINVAL, "rms_norm_image: null pointer");
+  if (dtype != MI355X_BF16 && dtype != MI355X_F16) return 1;
+  return MI355X_DISPATCH_HALF(dtype, [&] {
+    return launch_norm_image<scalar_t, false>(static_cast<scalar_t*>(image), static_cast<const scalar_t*>(input),
+                                              input_stride, nullptr, static_cast<const scalar_t*>(weight), epsilon,
+                                              num_tokens, hidden_size, static_cast<hipStream_t>(stream),
+                                              "rms_norm_image");
+  });
+}
+
+int mi355x_fused_add_rms_norm_image(void* image, const void* input, void* residual, const void* weight,
+                                    float epsilon, int num_tokens, int hidden_size, int64_t input_stride,
+                                    int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && hidden_size > 0, MI355X_EINVAL, "fused_add_rms_norm_image: bad sizes");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(image && input && residual && weight, MI355X_EINVAL, "fused_add_rms_norm_image: null pointer");
+  if (dtype != MI355X_BF16 && dtype != MI355X_F16) return 1;
+  return MI355X_DISPATCH_HALF(dtype, [&] {
+    return launch_norm_image<scalar_t, true>(static_cast<scalar_t*>(image), static_cast<const scalar_t*>(input),
+                                             input_stride, static_cast<scalar_t*>(residual),
+                                             static_cast<const scalar_t*>(weight), epsilon, num_tokens, hidden_size,
+                                             static_cast<hipStream_t>(stream), "fused_add_rms_norm_image");
   });
 }
 

@@ -303,6 +303,9 @@ class HotPathModel:
         # decode: slab sum + rotary + cache write of the new token inside the attention launch
         # (mi355x_paged_attention_fused_qkv) instead of a qkv_rope_cache launch in front of it; "0": two launches
         self.fuse_attn_qkv = os.environ.get("MI355X_FUSE_ATTN_QKV", "1") != "0"
+        # prefill: the norms in front of the qkv / gate_up GEMMs write the GEMM's activation operand image
+        # (mi355x_*rms_norm_image) instead of a row-major tensor the GEMM re-tiles; "0": row-major
+        self.norm_image = os.environ.get("MI355X_NORM_IMAGE", "1") != "0"
 
     # ---------------------------------------------------------------- helpers
     def _collectives(self) -> bool:
@@ -327,13 +330,19 @@ class HotPathModel:
         L = self.layers[i]
         cfg = self.cfg
         fuse = defer and self.cfg.tp == 1   # with tp > 1 the all-reduce sits between GEMM and norm
+        use_img = (not defer) and self.norm_image and x.shape[0] >= 1024 and pending[1] == 0 \
+            and L.qkv.image() is not None and L.gate_up.image() is not None
         if residual is None:
             residual = x.clone()
-            h = torch.empty_like(x)
-            ops.rms_norm(h, x, L.ln1, cfg.eps)
+            h = ops.rms_norm_image(x, L.ln1, cfg.eps) if use_img else None
+            if h is None:
+                h = torch.empty_like(x)
+                ops.rms_norm(h, x, L.ln1, cfg.eps)
         else:
-            ops.fused_add_rms_norm_slabs(x, residual, L.ln1, pending[0], pending[1], cfg.eps)
-            h = x
+            h = ops.fused_add_rms_norm_image(x, residual, L.ln1, cfg.eps) if use_img else None
+            if h is None:
+                ops.fused_add_rms_norm_slabs(x, residual, L.ln1, pending[0], pending[1], cfg.eps)
+                h = x
         attn = None
         if defer and x.dtype != torch.float32 and self.kv_dtype == "auto":
             # decode: slab sum + rotary + cache write in one launch (column-parallel GEMM: no
@@ -366,7 +375,11 @@ class HotPathModel:
             ops.fused_add_rms_norm_slabs(o, residual, L.ln2, slabs, sk, cfg.eps)
         else:
             o = self._all_reduce(L.o(attn.view(-1, L.q_size)))
-            ops.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
+            o_img = ops.fused_add_rms_norm_image(o, residual, L.ln2, cfg.eps) if use_img else None
+            if o_img is None:
+                ops.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
+            else:
+                o = o_img
         act = L.gate_up.silu_mul(o)            # prefill-sized AWQ: fused into the GEMM epilogue
         if act is None:
             gu = L.gate_up(o)
