@@ -446,6 +446,18 @@ int mi355x_fused_add_rms_norm_image(void* image, const void* input, void* residu
                                     float epsilon, int num_tokens, int hidden_size, int64_t input_stride,
                                     int dtype, mi355x_stream stream);
 
+/* paged_prefill_attention_image: mi355x_paged_prefill_attention whose output [tokens, num_heads * head_size] is
+ * written directly as the activation operand image of the prefill GEMM that follows (o_proj): the format of
+ * mi355x_rms_norm_image.  The caller zero-fills the last row tile when tokens % 16 != 0.  Same values as the
+ * row-major call.  head_size 128, block_size 16, 2-byte dtypes, no sliding window / soft-cap; otherwise returns 1
+ * (no error): run mi355x_paged_prefill_attention. */
+int mi355x_paged_prefill_attention_image(
+    void* image, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
+    const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
+    int max_num_blocks_per_seq, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+    int kv_cache_dtype, const float* k_scale, const float* v_scale, mi355x_stream stream);
+
 /* paged_attention_fused_qkv: qkv_rope_cache (above) folded into the decode attention launch that follows it:
  * the workgroup of (sequence, kv head) builds its query heads, k head and v head of the new token from the
  * qkv row (sk == 0) or its split-K slabs, applies the NeoX rotary to q and k, writes k / v into the cache slot

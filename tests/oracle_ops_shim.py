@@ -124,3 +124,7 @@ def rms_norm_image(x, weight, eps):
 
 def fused_add_rms_norm_image(x, residual, weight, eps):
     return None
+
+
+def paged_prefill_attention_image(*a, **k):
+    return None

@@ -141,3 +141,39 @@ def test_prefill_bench_chunk_properties_at_full_size():
     outp = torch.empty_like(q)
     ops().paged_prefill_attention(outp, qp, kc, vc, KVH, scale, bt[perm].contiguous(), sl, cu, L, BS)
     assert torch.equal(outp.view(S, L, H, D), out.view(S, L, H, D)[perm]), "sequence permutation"
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("lens,ctx", [([128, 300, 77, 1], 0), ([64, 200], 48)])
+def test_prefill_attention_image_is_bit_identical(dtype, lens, ctx):
+    """MI355X-side prefill fusion: the attention output written as o_proj's operand image == the row-major output
+    re-tiled, bit for bit (ragged query lengths, a total that is not a multiple of 16, cached context)."""
+    from vllm_metax_amd import _custom_ops as ops
+    H, KVH, D, BS = 8, 2, 128, 16
+    g = torch.Generator().manual_seed(len(lens) + ctx)
+    n = len(lens)
+    seq = [ctx + l for l in lens]
+    nblk = (max(seq) + BS - 1) // BS
+    nb = n * nblk + 2
+    d = dev()
+    kc = (torch.randn(nb, KVH, D // 8, BS, 8, generator=g) * 0.5).to(dtype).to(d)
+    vc = (torch.randn(nb, KVH, D, BS, generator=g) * 0.5).to(dtype).to(d)
+    bt = torch.randperm(nb, generator=g)[:n * nblk].to(torch.int32).view(n, nblk).to(d)
+    T = sum(lens)
+    q = (torch.randn(T, H, D, generator=g) * 0.5).to(dtype).to(d)
+    sl = torch.tensor(seq, dtype=torch.int32, device=d)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=d)
+    out = torch.empty_like(q)
+    ops.paged_prefill_attention(out, q, kc, vc, KVH, D ** -0.5, bt, sl, cu, max(lens), BS)
+    img = ops.paged_prefill_attention_image(q, kc, vc, KVH, D ** -0.5, bt, sl, cu, max(lens), BS)
+    assert img is not None and img.shape == (T, H * D)
+    mt, kt = (T + 15) // 16, H * D // 32
+    pad = torch.zeros(mt * 16, H * D, dtype=dtype, device=d)
+    pad[:T] = out.view(T, H * D)
+    t5 = pad.view(mt, 16, kt, 4, 8)
+    exp = torch.empty(mt, kt, 64, 8, dtype=dtype, device=d)
+    for lr in range(4):
+        gx = ((lr & 1) * 12) | (lr & 2)
+        for lc in range(16):
+            exp[:, :, lr * 16 + (lc ^ gx)] = t5[:, lc, :, lr]
+    assert torch.equal(img.data.view(mt, kt, 64, 8).view(torch.int16), exp.view(torch.int16))

@@ -689,6 +689,34 @@ def awq_gemm_silu_mul(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.
     return out
 
 
+def paged_prefill_attention_image(query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                                  num_kv_heads: int, scale: float, block_tables: torch.Tensor,
+                                  seq_lens: torch.Tensor, cu_seqlens_q: torch.Tensor, max_query_len: int,
+                                  block_size: int, kv_cache_dtype: str = "auto",
+                                  k_scale: Optional[torch.Tensor] = None,
+                                  v_scale: Optional[torch.Tensor] = None) -> Optional["PackedOperand"]:
+    """MI355X-side prefill fusion: paged_prefill_attention whose output [tokens, heads * head_size] is written as
+    the activation operand image of the GEMM that consumes it (o_proj).  None: not applicable to these shapes."""
+    _dev(query, key_cache, value_cache, block_tables, seq_lens, cu_seqlens_q)
+    if query.dtype not in (torch.bfloat16, torch.float16) or query.dim() != 3:
+        return None
+    kvd, ks, vs = _kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale)
+    t, h, d = query.shape
+    mt = (t + 15) // 16
+    image = torch.empty(mt * 16 * h * d, dtype=query.dtype, device=query.device)
+    if t % 16:
+        image[(mt - 1) * 16 * h * d:].zero_()        # rows past the last token of the last row tile
+    rc = _abi.load().mi355x_paged_prefill_attention_image(
+        _ptr(image), _ptr(query), _ptr(key_cache), _ptr(value_cache), seq_lens.size(0), h, num_kv_heads, d,
+        block_size, float(scale), _ptr(block_tables), _ptr(seq_lens), _ptr(cu_seqlens_q), max_query_len,
+        block_tables.size(1), query.stride(0), key_cache.stride(0), key_cache.stride(1), _dt(query), kvd, ks, vs,
+        _stream())
+    if rc == 1:
+        return None
+    _abi.check(rc, "paged_prefill_attention_image")
+    return PackedOperand(image, t, h * d)
+
+
 def _norm_image(name: str, x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor,
                 epsilon: float) -> Optional["PackedOperand"]:
     _dev(x, residual, weight)

@@ -94,7 +94,11 @@ constexpr int kPfKvTile = 32;   // keys per stage (2 cache blocks)
 constexpr int kPfStages = 3;    // LDS ring depth (16 KiB per stage)
 constexpr float kNegBig = -1.0e30f;
 
-template <typename T, bool KV8>
+// IMG: `out` is the activation operand image of the prefill GEMM that consumes the attention output (o_proj):
+// [row tile of 16 tokens][k tile of 32][64 slots of 8 elements], slot lr * 16 + (lc ^ g(lr)) = O[16 mt + lc][32 kt +
+// 8 lr ..] over the [tokens, num_heads * 128] matrix — the re-tiling launch in front of that GEMM disappears, and
+// the epilogue's stores become two 256-byte runs per instruction instead of sixteen 32-byte ones.
+template <typename T, bool KV8, bool IMG = false>
 __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     T* __restrict__ out, const T* __restrict__ q, const void* __restrict__ k_cache_v,
     const void* __restrict__ v_cache_v, int num_heads, int num_kv_heads, float scale,
@@ -366,12 +370,29 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     float inv = 1.0f / l;
     if constexpr (KV8) inv *= *v_scale;
     if (qrow[qt] < q_len) {
+      if constexpr (IMG) {
+        // element (token t, column head * 128 + 16 dt + 4 lr + j): row tile t >> 4, row t & 15; k tile
+        // head * 4 + (dt >> 1), k group 2 (dt & 1) + (lr >> 1), half (lr & 1) of that 16-byte slot
+        const int t = q_begin + qrow[qt];
+        const int kt32 = num_heads * (kPfD / 32);
+        uint2* img = reinterpret_cast<uint2*>(out) + ((int64_t)(t >> 4) * kt32 + head * 4) * 128 + (lr & 1);
+        const int lcp = t & 15;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          const uint2 v = make_uint2(MfmaQK<T>::pack(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv),
+                                     MfmaQK<T>::pack(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv));
+          const int lrp = 2 * (dt & 1) + (lr >> 1);
+          const int slot = lrp * 16 + (lcp ^ (((lrp & 1) * 12) | (lrp & 2)));
+          img[((dt >> 1) * 64 + slot) * 2] = v;
+        }
+      } else {
       T* op = out + (int64_t)(q_begin + qrow[qt]) * out_stride + (int64_t)head * kPfD + 4 * lr;
 #pragma unroll
       for (int dt = 0; dt < 8; ++dt) {
         const uint2 v = make_uint2(MfmaQK<T>::pack(oacc[qt][dt][0] * inv, oacc[qt][dt][1] * inv),
                                    MfmaQK<T>::pack(oacc[qt][dt][2] * inv, oacc[qt][dt][3] * inv));
         *reinterpret_cast<uint2*>(op + 16 * dt) = v;
+      }
       }
     }
   }
@@ -462,13 +483,13 @@ __global__ __launch_bounds__(64) void paged_prefill_generic_kernel(
 
 using namespace mi355x;
 
-extern "C" int mi355x_paged_prefill_attention(
+static int paged_prefill_impl(
     void* out, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
     int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
     const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
     int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
     int64_t kv_head_stride, int dtype, int kv_cache_dtype, const float* k_scale,
-    const float* v_scale, int sliding_window, float softcap, mi355x_stream stream) {
+    const float* v_scale, int sliding_window, float softcap, mi355x_stream stream, bool image) {
   MI355X_REQUIRE(sliding_window >= 0 && softcap >= 0.f, MI355X_EINVAL,
                  "paged_prefill_attention: sliding_window / softcap must be >= 0 (0 = off)");
   MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3,
@@ -496,11 +517,28 @@ extern "C" int mi355x_paged_prefill_attention(
                       reinterpret_cast<uintptr_t>(value_cache)) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
                     kv_block_stride % (kv8 ? 16 : 8) == 0 && kv_head_stride % (kv8 ? 16 : 8) == 0;
+  if (image && !(fast && (reinterpret_cast<uintptr_t>(out) & 15) == 0)) return 1;   // image form: fast path only
   if (fast) {
     const int q_blocks = (max_query_len + kPfQTile - 1) / kPfQTile;
     dim3 grid(num_seqs * q_blocks * num_heads), block(256);
     const size_t smem = (size_t)kPfStages * 4 * (kv8 ? 2048 : 4096);   // ring of 16- / 8-KiB stages
     return MI355X_DISPATCH_HALF(dtype, [&] {
+      if (image) {
+        if (kv8) {
+          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, true>), grid, block, smem, s,
+                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
+                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
+                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
+                             kv_block_stride, kv_head_stride, k_scale, v_scale);
+        } else {
+          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, false, true>), grid, block, smem, s,
+                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
+                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
+                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
+                             kv_block_stride, kv_head_stride, k_scale, v_scale);
+        }
+        return check_launch("paged_prefill_attention_image");
+      }
       if (kv8) {
         hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true>), grid, block, smem, s,
                            static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
@@ -541,4 +579,30 @@ extern "C" int mi355x_paged_prefill_attention(
     }
     return check_launch("paged_prefill_attention(generic)");
   });
+}
+
+extern "C" int mi355x_paged_prefill_attention(
+    void* out, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
+    const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
+    int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int dtype, int kv_cache_dtype, const float* k_scale,
+    const float* v_scale, int sliding_window, float softcap, mi355x_stream stream) {
+  return paged_prefill_impl(out, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads, head_size,
+                            block_size, scale, block_tables, seq_lens, cu_seqlens_q, max_query_len,
+                            max_num_blocks_per_seq, q_stride, out_stride, kv_block_stride, kv_head_stride, dtype,
+                            kv_cache_dtype, k_scale, v_scale, sliding_window, softcap, stream, false);
+}
+
+// returns 1 (no error) when the image form does not apply: run mi355x_paged_prefill_attention instead
+extern "C" int mi355x_paged_prefill_attention_image(
+    void* image, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
+    const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
+    int max_num_blocks_per_seq, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
+    int kv_cache_dtype, const float* k_scale, const float* v_scale, mi355x_stream stream) {
+  return paged_prefill_impl(image, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads, head_size,
+                            block_size, scale, block_tables, seq_lens, cu_seqlens_q, max_query_len,
+                            max_num_blocks_per_seq, q_stride, /*out_stride (unused)*/ 4, kv_block_stride,
+                            kv_head_stride, dtype, kv_cache_dtype, k_scale, v_scale, 0, 0.f, stream, true);
 }

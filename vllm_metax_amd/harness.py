@@ -374,7 +374,7 @@ class HotPathModel:
             o, slabs, sk = L.o.deferred(attn.view(-1, L.q_size))
             ops.fused_add_rms_norm_slabs(o, residual, L.ln2, slabs, sk, cfg.eps)
         else:
-            o = self._all_reduce(L.o(attn.view(-1, L.q_size)))
+            o = self._all_reduce(L.o(attn if isinstance(attn, ops.PackedOperand) else attn.view(-1, L.q_size)))
             o_img = ops.fused_add_rms_norm_image(o, residual, L.ln2, cfg.eps) if use_img else None
             if o_img is None:
                 ops.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
@@ -423,6 +423,13 @@ class HotPathModel:
         residual = None
 
         def attn_fn(i, q3):
+            if self.norm_image and q3.shape[0] >= 1024 and self.layers[i].o.image() is not None:
+                # the attention output goes straight into o_proj's activation operand image
+                img = ops.paged_prefill_attention_image(q3, self.k_cache[i], self.v_cache[i],
+                                                        self.layers[i].kv_heads, self.scale, bt, seq_lens, cu,
+                                                        q_len, self.BLOCK, self.kv_dtype, self.k_scale, self.v_scale)
+                if img is not None:
+                    return img
             out = torch.empty_like(q3)
             ops.paged_prefill_attention(out, q3, self.k_cache[i], self.v_cache[i],
                                         self.layers[i].kv_heads, self.scale, bt, seq_lens, cu,
