@@ -149,13 +149,23 @@ def instrument(model, timer: EventTimer):
     harness.QLinear.silu_mul = timed_silu
     harness.QLinear.deferred = timed_deferred
 
-    def wrap(opname, cost):
+    def wrap(opname, cost, record_as=None):
+        """record_as: the fused / image forms of an op are recorded under the name of the op they stand for; a
+        call that reports "not applicable" (None / False: nothing was launched) leaves no record."""
         fn = getattr(ops, opname)
+        name = record_as or opname
 
         def w(*a, **k):
             flops, nbytes = cost(*a, **k)
-            return timer.time(opname, flops, nbytes, lambda: fn(*a, **k))
+            out = timer.time(name, flops, nbytes, lambda: fn(*a, **k))
+            if record_as and (out is None or out is False) and timer.enabled and timer.records \
+                    and timer.records[-1][0] == name:
+                timer.records.pop()
+            return out
         setattr(ops, opname, w)
+        if opname == "paged_attention_fused_qkv":
+            from vllm_metax_amd.attention import backend
+            backend.ops = ops          # (the backend calls it through its own `ops` reference: same module)
 
     def cost_prefill(out, q, kc, vc, kvh, scale, bt, sl, cu, max_q, bs, *a, **k):
         T, H, D = q.shape
@@ -179,6 +189,23 @@ def instrument(model, timer: EventTimer):
         return c
 
     wrap("paged_prefill_attention", cost_prefill)
+    wrap("paged_prefill_attention_image",
+         lambda q, kc, vc, kvh, scale, bt, sl, cu, max_q, bs, *a, **k:
+         cost_prefill(None, q, kc, vc, kvh, scale, bt, sl, cu, max_q, bs), record_as="paged_prefill_attention")
+
+    def cost_decode_fused(out, es, ml, tmp, qkv, slabs, sk, positions, cos_sin, slots, kc, vc, nh, kvh, scale, bt,
+                          sl, bs, max_len, partitioned):
+        # the attention bytes (as paged_attention_v1 / _v2) + the qkv row / slabs of the folded qkv_rope_cache
+        S, D = qkv.shape[0], kc.shape[2] * kc.shape[4]
+        mean_len = model.mean_decode_len_for_cost
+        nbytes = S * mean_len * kvh * D * 2 * kc.element_size() + 2.0 * S * nh * D * 2 \
+            + qkv.numel() * (4.0 * sk if sk > 0 else 2.0)
+        return 4.0 * S * mean_len * nh * D, nbytes
+    wrap("paged_attention_fused_qkv", cost_decode_fused, record_as="paged_attention_v1")
+    wrap("rms_norm_image", lambda x, w, eps: (0.0, float(x.numel() * x.element_size() * 2)), record_as="rms_norm")
+    wrap("fused_add_rms_norm_image", lambda x, r, w, eps: (0.0, float(x.numel() * x.element_size() * 5)),
+         record_as="fused_add_rms_norm")
+    wrap("greedy_advance", lambda logits, *a, **k: (0.0, float(logits.numel() * logits.element_size())))
     wrap("paged_attention_v2", cost_decode)
     wrap("paged_attention_v1",
          lambda out, q, kc, vc, kvh, scale, bt, sl, bs, max_len, *a, **k:

@@ -268,18 +268,27 @@ __global__ __launch_bounds__(1024) void rms_norm_image_kernel(
   const float inv_rms = rsqrtf(ss / hidden_size + epsilon);
   const int kt32 = hidden_size >> 5;
   uint4* img = reinterpret_cast<uint4*>(image) + (int64_t)blockIdx.x * kt32 * 64;
+  // One (k, c) step of the 16 waves = chunks 256 c + 64 k .. + 63 of 16 rows = 16 COMPLETE pieces (k tiles
+  // 64 c + 16 k .. + 15): exchanged through LDS so that every wave stores one whole 1-KiB piece linearly
+  // (direct 16-byte stores at slot addresses ran the kernel at 3.3 TB/s instead of the row-major 5.7).
+  __shared__ uint4 stage[2][16 * 64];
+  int buf = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
-      const int ch = c * 256 + 64 * k + lane;            // 16-byte chunk of the row
       T ov[V];
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         const T n = from_f32_rounded<T>(x[k][c][j] * inv_rms);
         ov[j] = live ? mul_t<T>(n, wreg[k][c][j]) : from_f32<T>(0.f);   // rows >= num_tokens of the tile: zero
       }
-      img[(ch >> 2) * 64 + norm_frag_swz(ch & 3, lc)] = *reinterpret_cast<const uint4*>(ov);
+      // chunk 256 c + 64 k + lane of row lc: piece (lane >> 2) of this step, k group lane & 3
+      stage[buf][(lane >> 2) * 64 + norm_frag_swz(lane & 3, lc)] = *reinterpret_cast<const uint4*>(ov);
+      __syncthreads();   // (two buffers: the next step writes the other one; this one is rewritten two steps on,
+                         //  behind the next step's barrier, which every wave reaches after its reads below)
+      img[(64 * c + 16 * k + lc) * 64 + lane] = stage[buf][lc * 64 + lane];
+      buf ^= 1;
     }
   }
 }
