@@ -450,13 +450,17 @@ int mi355x_fused_add_rms_norm_image(void* image, const void* input, void* residu
  * written directly as the activation operand image of the prefill GEMM that follows (o_proj): the format of
  * mi355x_rms_norm_image.  The caller zero-fills the last row tile when tokens % 16 != 0.  Same values as the
  * row-major call.  head_size 128, block_size 16, 2-byte dtypes, no sliding window / soft-cap; otherwise returns 1
- * (no error): run mi355x_paged_prefill_attention. */
+ * (no error): run mi355x_paged_prefill_attention.
+ * positions / cos_sin_cache non-NULL ([tokens] int64, [max_pos, 128] scalar_t): `query` holds the UN-rotated rows
+ * and the NeoX rotary (rot_dim 128) is applied while they are loaded — the caller then runs rotary_embedding on
+ * the key rows only (they go to the cache); same bits as rotating q first. */
 int mi355x_paged_prefill_attention_image(
     void* image, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
     int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
     const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
     int max_num_blocks_per_seq, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
-    int kv_cache_dtype, const float* k_scale, const float* v_scale, mi355x_stream stream);
+    int kv_cache_dtype, const float* k_scale, const float* v_scale, const int64_t* positions,
+    const void* cos_sin_cache, mi355x_stream stream);
 
 /* paged_attention_fused_qkv: qkv_rope_cache (above) folded into the decode attention launch that follows it:
  * the workgroup of (sequence, kv head) builds its query heads, k head and v head of the new token from the

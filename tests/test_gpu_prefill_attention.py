@@ -177,3 +177,12 @@ def test_prefill_attention_image_is_bit_identical(dtype, lens, ctx):
         for lc in range(16):
             exp[:, :, lr * 16 + (lc ^ gx)] = t5[:, lc, :, lr]
     assert torch.equal(img.data.view(mt, kt, 64, 8).view(torch.int16), exp.view(torch.int16))
+    # query rotary applied while the rows are loaded == rotary_embedding on q first
+    pos = torch.randint(0, 4096, (T,), generator=g).to(d)
+    cos_sin = torch.randn(4096, D, generator=g).to(dtype).to(d)
+    q_rot = q.clone()
+    ops.rotary_embedding(pos, q_rot.view(T, H * D), None, D, cos_sin, True)
+    img_a = ops.paged_prefill_attention_image(q_rot, kc, vc, KVH, D ** -0.5, bt, sl, cu, max(lens), BS)
+    img_b = ops.paged_prefill_attention_image(q, kc, vc, KVH, D ** -0.5, bt, sl, cu, max(lens), BS,
+                                              positions=pos, cos_sin_cache=cos_sin)
+    assert torch.equal(img_a.data.view(torch.int16), img_b.data.view(torch.int16))

@@ -694,10 +694,18 @@ def paged_prefill_attention_image(query: torch.Tensor, key_cache: torch.Tensor, 
                                   seq_lens: torch.Tensor, cu_seqlens_q: torch.Tensor, max_query_len: int,
                                   block_size: int, kv_cache_dtype: str = "auto",
                                   k_scale: Optional[torch.Tensor] = None,
-                                  v_scale: Optional[torch.Tensor] = None) -> Optional["PackedOperand"]:
+                                  v_scale: Optional[torch.Tensor] = None,
+                                  positions: Optional[torch.Tensor] = None,
+                                  cos_sin_cache: Optional[torch.Tensor] = None) -> Optional["PackedOperand"]:
     """MI355X-side prefill fusion: paged_prefill_attention whose output [tokens, heads * head_size] is written as
-    the activation operand image of the GEMM that consumes it (o_proj).  None: not applicable to these shapes."""
-    _dev(query, key_cache, value_cache, block_tables, seq_lens, cu_seqlens_q)
+    the activation operand image of the GEMM that consumes it (o_proj).  None: not applicable to these shapes.
+    With positions + cos_sin_cache the query rows are taken UN-rotated and the NeoX rotary is applied while they
+    are loaded (the caller rotates the key rows only)."""
+    _dev(query, key_cache, value_cache, block_tables, seq_lens, cu_seqlens_q, positions, cos_sin_cache)
+    if positions is not None:
+        if positions.dtype != torch.int64 or cos_sin_cache is None or cos_sin_cache.dtype != query.dtype \
+                or cos_sin_cache.size(-1) != query.size(-1) or not cos_sin_cache.is_contiguous():
+            return None
     if query.dtype not in (torch.bfloat16, torch.float16) or query.dim() != 3:
         return None
     kvd, ks, vs = _kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale)
@@ -710,7 +718,8 @@ def paged_prefill_attention_image(query: torch.Tensor, key_cache: torch.Tensor, 
         _ptr(image), _ptr(query), _ptr(key_cache), _ptr(value_cache), seq_lens.size(0), h, num_kv_heads, d,
         block_size, float(scale), _ptr(block_tables), _ptr(seq_lens), _ptr(cu_seqlens_q), max_query_len,
         block_tables.size(1), query.stride(0), key_cache.stride(0), key_cache.stride(1), _dt(query), kvd, ks, vs,
-        _stream())
+        _ptr(positions) if positions is not None else None,
+        _ptr(cos_sin_cache) if positions is not None else None, _stream())
     if rc == 1:
         return None
     _abi.check(rc, "paged_prefill_attention_image")

@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     const int* __restrict__ block_tables, const int* __restrict__ seq_lens,
     const int* __restrict__ cu_seqlens_q, int max_num_blocks_per_seq, int q_blocks_per_seq,
     int64_t q_stride, int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-    const float* __restrict__ k_scale, const float* __restrict__ v_scale) {
+    const float* __restrict__ k_scale, const float* __restrict__ v_scale,
+    const int64_t* __restrict__ positions = nullptr, const T* __restrict__ cos_sin_cache = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [stage][K: 2 blocks | V: 2 blocks], a block = 4 KiB (scalar_t cache) or 2 KiB (fp8 cache)
   uint4* lds = reinterpret_cast<uint4*>(smem);
@@ -150,6 +151,24 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     const T* qp = q + (int64_t)(q_begin + r) * q_stride + (int64_t)head * kPfD + 8 * lr;
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) qf[qt][ds] = *reinterpret_cast<const uint4*>(qp + 32 * ds);
+    if (positions != nullptr) {
+      // NeoX rotary of the query rows on the fly (rot_dim = 128): element d pairs with d + 64, i.e. fragment ds
+      // with ds + 2 of the same lane; cos | sin of the row's position (the arithmetic of rotary_embedding:
+      // csrc/pos_encoding_kernels.cu:10-34) — the q half of the rotary launch in front of this kernel
+      const T* cs_row = cos_sin_cache + positions[q_begin + r] * kPfD + 8 * lr;
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        Vec16<T> x, y;
+        *reinterpret_cast<uint4*>(x.e) = qf[qt][ds];
+        *reinterpret_cast<uint4*>(y.e) = qf[qt][ds + 2];
+        const Vec16<T> cs = load16(cs_row + 32 * ds);
+        const Vec16<T> sn = load16(cs_row + 64 + 32 * ds);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rot_pair<T>(x.e[j], y.e[j], cs.e[j], sn.e[j]);
+        qf[qt][ds] = *reinterpret_cast<const uint4*>(x.e);
+        qf[qt][ds + 2] = *reinterpret_cast<const uint4*>(y.e);
+      }
+    }
   }
 
   f32x4_t oacc[2][8];
@@ -489,7 +508,8 @@ static int paged_prefill_impl(
     const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
     int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
     int64_t kv_head_stride, int dtype, int kv_cache_dtype, const float* k_scale,
-    const float* v_scale, int sliding_window, float softcap, mi355x_stream stream, bool image) {
+    const float* v_scale, int sliding_window, float softcap, mi355x_stream stream, bool image,
+    const int64_t* positions = nullptr, const void* cos_sin_cache = nullptr) {
   MI355X_REQUIRE(sliding_window >= 0 && softcap >= 0.f, MI355X_EINVAL,
                  "paged_prefill_attention: sliding_window / softcap must be >= 0 (0 = off)");
   MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3,
@@ -529,13 +549,15 @@ static int paged_prefill_impl(
                              static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
                              value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
                              cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                             kv_block_stride, kv_head_stride, k_scale, v_scale);
+                             kv_block_stride, kv_head_stride, k_scale, v_scale, positions,
+                             static_cast<const scalar_t*>(cos_sin_cache));
         } else {
           hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, false, true>), grid, block, smem, s,
                              static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
                              value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
                              cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                             kv_block_stride, kv_head_stride, k_scale, v_scale);
+                             kv_block_stride, kv_head_stride, k_scale, v_scale, positions,
+                             static_cast<const scalar_t*>(cos_sin_cache));
         }
         return check_launch("paged_prefill_attention_image");
       }
@@ -600,9 +622,15 @@ extern "C" int mi355x_paged_prefill_attention_image(
     int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
     const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
     int max_num_blocks_per_seq, int64_t q_stride, int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
-    int kv_cache_dtype, const float* k_scale, const float* v_scale, mi355x_stream stream) {
+    int kv_cache_dtype, const float* k_scale, const float* v_scale, const int64_t* positions,
+    const void* cos_sin_cache, mi355x_stream stream) {
+  MI355X_REQUIRE((positions == nullptr) == (cos_sin_cache == nullptr), MI355X_EINVAL,
+                 "paged_prefill_attention_image: positions and cos_sin_cache go together");
+  MI355X_REQUIRE((reinterpret_cast<uintptr_t>(cos_sin_cache) & 15) == 0, MI355X_EINVAL,
+                 "paged_prefill_attention_image: cos_sin_cache must be 16-byte aligned");
   return paged_prefill_impl(image, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads, head_size,
                             block_size, scale, block_tables, seq_lens, cu_seqlens_q, max_query_len,
                             max_num_blocks_per_seq, q_stride, /*out_stride (unused)*/ 4, kv_block_stride,
-                            kv_head_stride, dtype, kv_cache_dtype, k_scale, v_scale, 0, 0.f, stream, true);
+                            kv_head_stride, dtype, kv_cache_dtype, k_scale, v_scale, 0, 0.f, stream, true, positions,
+                            cos_sin_cache);
 }

@@ -364,7 +364,11 @@ class HotPathModel:
             q = qkv[:, :L.q_size]
             k = qkv[:, L.q_size:L.q_size + L.kv_size]
             v = qkv[:, L.q_size + L.kv_size:]
-            ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin, True)
+            if getattr(self, "_pf_rope_q_in_attn", False) and not defer:
+                # prefill: the attention kernel rotates the query rows while it loads them; only k here
+                ops.rotary_embedding(positions, k, None, cfg.head_dim, self.cos_sin, True)
+            else:
+                ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin, True)
             ops.reshape_and_cache(k.view(-1, L.kv_heads, cfg.head_dim), v.view(-1, L.kv_heads, cfg.head_dim),
                                   self.k_cache[i], self.v_cache[i], slots, self.kv_dtype, self.k_scale,
                                   self.v_scale)
@@ -422,14 +426,24 @@ class HotPathModel:
         x = self.embed[token_ids.reshape(-1)]
         residual = None
 
+        # q rotary inside the attention kernel (with the image output): decided once per chunk
+        self._pf_rope_q_in_attn = bool(self.norm_image and n * q_len >= 1024 and self.cfg.head_dim == 128
+                                       and self.BLOCK == 16 and self.dtype != torch.float32
+                                       and not self.fuse_prefill_rope
+                                       and all(L.o.image() is not None for L in self.layers[:1]))
+
         def attn_fn(i, q3):
+            rope = self._pf_rope_q_in_attn
             if self.norm_image and q3.shape[0] >= 1024 and self.layers[i].o.image() is not None:
                 # the attention output goes straight into o_proj's activation operand image
                 img = ops.paged_prefill_attention_image(q3, self.k_cache[i], self.v_cache[i],
                                                         self.layers[i].kv_heads, self.scale, bt, seq_lens, cu,
-                                                        q_len, self.BLOCK, self.kv_dtype, self.k_scale, self.v_scale)
+                                                        q_len, self.BLOCK, self.kv_dtype, self.k_scale, self.v_scale,
+                                                        pos if rope else None, self.cos_sin if rope else None)
                 if img is not None:
                     return img
+            if rope:      # the image form did not apply after all: rotate q now
+                ops.rotary_embedding(pos, q3.view(q3.shape[0], -1), None, self.cfg.head_dim, self.cos_sin, True)
             out = torch.empty_like(q3)
             ops.paged_prefill_attention(out, q3, self.k_cache[i], self.v_cache[i],
                                         self.layers[i].kv_heads, self.scale, bt, seq_lens, cu,
