@@ -285,6 +285,28 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   // physical block ids of the partition first: their latency overlaps with the q staging / prologue below
   const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
   for (int i = tid; i < end_block - start_block; i += nthreads) bt_s[i] = block_table[start_block + i];
+  // Work split: block (start_block + i * nwaves + wave) is the i-th item of this wave (round robin:
+  // the waves' loads differ by at most one block).  K and V blocks go through TWO register buffers:
+  // the load of item i + 2 is issued as soon as item i has been consumed, so one to two 4-KiB blocks
+  // per wave (64-128 KiB per CU) are in flight all the time instead of "load two, wait, compute two".
+  const int t_in_blk = lane % BS;     // token of this lane inside a block
+  const int csub = lane / BS;         // chunk phase of this lane
+  const int nblk_part = end_block - start_block;
+  const int nitems = wave < nblk_part ? (nblk_part - wave + nwaves - 1) / nwaves : 0;
+  auto item_block = [&](int i) { return i * nwaves + wave; };     // index inside the partition
+  constexpr int NIK = NI > 0 ? NI : 1;
+  uint4 ka[NIK], kb[NIK];
+  auto load_k = [&](int i, uint4 (&kk)[NIK]) {
+    const int64_t pb = bt_s[item_block(i)];
+    const CT* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int c = csub + LPT * j;
+      const int cc = (c < C) ? c : 0;
+      kk[j] = ld_kv16(kp + (cc * BS + t_in_blk) * X);
+    }
+  };
+  bool pre0 = false, pre1 = false;    // FQ: K blocks 0 / 1 of this wave were requested inside the prologue
   if constexpr (FQ) {
     // ---- q | k | v of the new token: [slab sum ->] T, rotary on q and k, k / v into the cache ----
     // (host: tiles == 1 and nheads == GT; rows of q_s: GT query heads, then the k head, then the v head)
@@ -315,7 +337,16 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
       }
       store16(q_s + hs * D + c * XT, v);
     }
-    __syncthreads();
+    __syncthreads();   // (also publishes bt_s)
+    {
+      // the first two K blocks of this wave go out NOW — unless one of them is the block that receives the new
+      // token (written below): their latency overlaps with the rotary, the cache write and its fence
+      const int new_local = (seq_len - 1) / BS - start_block;
+      pre0 = nitems > 0 && item_block(0) != new_local;
+      pre1 = nitems > 1 && item_block(1) != new_local;
+      if (pre0) load_k(0, ka);
+      if (pre1) load_k(1, kb);
+    }
     if (tid < (GT + 1) * cph) {     // (GT + 1) * cph <= 40 <= the workgroup size: one chunk pair per thread
       const int h = tid / cph;
       const int c = tid - h * cph;
@@ -360,18 +391,9 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   }
 
   // =========================== QK^T ==============================================
-  const int t_in_blk = lane % BS;     // token of this lane inside a block
-  const int csub = lane / BS;         // chunk phase of this lane
   float qk_max[GT];
 #pragma unroll
   for (int g = 0; g < GT; ++g) qk_max[g] = -3.402823466e+38f;
-  // Work split: block (start_block + i * nwaves + wave) is the i-th item of this wave (round robin:
-  // the waves' loads differ by at most one block).  K and V blocks go through TWO register buffers:
-  // the load of item i + 2 is issued as soon as item i has been consumed, so one to two 4-KiB blocks
-  // per wave (64-128 KiB per CU) are in flight all the time instead of "load two, wait, compute two".
-  const int nblk_part = end_block - start_block;
-  const int nitems = wave < nblk_part ? (nblk_part - wave + nwaves - 1) / nwaves : 0;
-  auto item_block = [&](int i) { return i * nwaves + wave; };     // index inside the partition
 
   if constexpr (HS != 0) {
     // q chunks of this lane live in registers for the whole kernel
@@ -388,17 +410,7 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
         }
       }
     }
-    auto load_k = [&](int i, uint4 (&kk)[NI]) {
-      const int64_t pb = bt_s[item_block(i)];
-      const CT* kp = k_cache + pb * kv_block_stride + (int64_t)kv_head * kv_head_stride;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int c = csub + LPT * j;
-        const int cc = (c < C) ? c : 0;
-        kk[j] = ld_kv16(kp + (cc * BS + t_in_blk) * X);
-      }
-    };
-    auto qk_block = [&](int i, const uint4 (&kk)[NI]) {
+    auto qk_block = [&](int i, const uint4 (&kk)[NIK]) {
       float acc[GT];
 #pragma unroll
       for (int g = 0; g < GT; ++g) acc[g] = 0.f;
@@ -427,9 +439,8 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
         }
       }
     };
-    uint4 ka[NI], kb[NI];
-    if (nitems > 0) load_k(0, ka);
-    if (nitems > 1) load_k(1, kb);
+    if (nitems > 0 && !pre0) load_k(0, ka);
+    if (nitems > 1 && !pre1) load_k(1, kb);
     for (int i = 0; i < nitems; i += 2) {
       qk_block(i, ka);
       if (i + 2 < nitems) load_k(i + 2, ka);
