@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 2
+#define MI355X_ABI_VERSION 3   /* 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive) */
 
 typedef enum {
   MI355X_F16 = 0,  /* IEEE half  (torch.float16)  */
