@@ -538,3 +538,26 @@ def test_norm_image_not_applicable_returns_none():
     x2 = torch.randn(1024, 1024, device=d).to(torch.bfloat16)
     assert ops().rms_norm_image(x2, torch.ones(1024, device=d, dtype=torch.bfloat16), 1e-5) is None
     assert ops().rms_norm_image(x.float().repeat(16, 1), w.float(), 1e-5) is None
+
+
+def test_greedy_advance_nan_and_inf_rows():
+    """torch.argmax order on non-finite rows: a NaN beats every number (first NaN wins), -inf rows give index 0 —
+    the token must always be inside the vocabulary (the next step gathers an embedding row with it)."""
+    d = dev()
+    vocab, bs = 1000, 16
+    logits = torch.randn(5, vocab)
+    logits[0, :] = float("nan")
+    logits[1, 777] = float("nan"); logits[1, 3] = float("inf")
+    logits[2, :] = float("-inf")
+    logits[3, 500] = float("inf"); logits[3, 900] = float("inf")
+    logits[4, 10] = float("nan"); logits[4, 5] = float("nan")
+    for dtype in (torch.bfloat16, torch.float32):
+        lg = logits.to(dtype).to(d)
+        tok = torch.full((5,), -1, dtype=torch.int64, device=d)
+        pos = torch.zeros(5, dtype=torch.int64, device=d)
+        seq = torch.ones(5, dtype=torch.int32, device=d)
+        slots = torch.zeros(5, dtype=torch.int64, device=d)
+        bt = torch.arange(5 * 4, dtype=torch.int32, device=d).view(5, 4)
+        ops().greedy_advance(lg, tok, pos, seq, slots, bt, bs)
+        assert tok.cpu().tolist() == [0, 777, 0, 500, 5]
+        assert tok.cpu().tolist() == torch.argmax(lg.float().cpu(), dim=-1).tolist()

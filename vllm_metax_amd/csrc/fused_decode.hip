@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
 }
 
 // ---- greedy_advance: what follows the lm_head of a greedy decode step, one launch -----------------
-// token = argmax(logits[row]) (lowest index among equal maxima); position, sequence length += 1; slot of
+// token = argmax(logits[row]) (torch.argmax order: NaN first, lowest index among equal maxima); position, sequence length += 1; slot of
 // the token the next step writes = block_table[row][new position / block_size] * block_size + remainder.
 // One workgroup per row: lanes stride over 16-byte chunks of the row, (value, index) pairs reduced with
 // max-by-value / min-by-index.
@@ -131,8 +131,12 @@ __global__ __launch_bounds__(1024) void greedy_advance_kernel(
   const T* lr = logits + (int64_t)row * logits_stride;
   float best = -INFINITY;
   int bidx = 0x7fffffff;
+  // order of torch.argmax: a NaN beats every number, the lowest index wins among equals (and among NaNs) — a row of
+  // NaNs must still yield an index inside the vocabulary (the next step gathers the embedding row with it)
   auto take = [&](float v, int i) {
-    if (v > best || (v == best && i < bidx)) best = v, bidx = i;
+    const bool vn = v != v, bn = best != best;
+    const bool better = vn ? (!bn || i < bidx) : (!bn && (v > best || (v == best && i < bidx)));
+    if (better) best = v, bidx = i;
   };
   const bool vec = (reinterpret_cast<uintptr_t>(lr) & 15) == 0;
   const int nvec = vec ? vocab / V : 0;
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(1024) void greedy_advance_kernel(
   if (threadIdx.x == 0) {
     const int nw = (blockDim.x + 63) >> 6;
     for (int w = 1; w < nw; ++w) take(s_val[w], s_idx[w]);
-    tokens[row] = bidx;
+    tokens[row] = bidx < vocab ? bidx : 0;
     const int64_t pos = positions[row] + 1;
     positions[row] = pos;
     seq_lens[row] += 1;
