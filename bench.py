@@ -206,6 +206,9 @@ def instrument(model, timer: EventTimer):
     wrap("fused_add_rms_norm_image", lambda x, r, w, eps: (0.0, float(x.numel() * x.element_size() * 5)),
          record_as="fused_add_rms_norm")
     wrap("greedy_advance", lambda logits, *a, **k: (0.0, float(logits.numel() * logits.element_size())))
+    wrap("rotary_reshape_and_cache",
+         lambda pos, key, value, kc, *a, **k: (0.0, 2.0 * key.numel() * (2 + kc.element_size())),
+         record_as="reshape_and_cache")
     wrap("paged_attention_v2", cost_decode)
     wrap("paged_attention_v1",
          lambda out, q, kc, vc, kvh, scale, bt, sl, bs, max_len, *a, **k:

@@ -432,6 +432,16 @@ int mi355x_qkv_rope_cache(void* qkv, int64_t qkv_stride, const float* slabs, int
                           int64_t key_block_stride, int64_t value_block_stride, int dtype,
                           mi355x_stream stream);
 
+/* rotary_reshape_and_cache (prefill): rotary_embedding on the KEY rows + reshape_and_cache in one launch — the
+ * rotated keys go only to the cache (`key` is not modified; the prefill attention reads K from the cache and can
+ * rotate its query rows itself: mi355x_paged_prefill_attention_image).  NeoX style, rot_dim == head_size, x-split
+ * cache with x == 8 (2-byte dtypes); otherwise returns 1 (no error): run the two ops.  Same bits in the cache. */
+int mi355x_rotary_reshape_and_cache(const void* key, const void* value, void* key_cache, void* value_cache,
+                                    const int64_t* slot_mapping, const int64_t* positions,
+                                    const void* cos_sin_cache, int num_tokens, int64_t key_stride,
+                                    int64_t value_stride, int num_heads, int head_size, int block_size, int x,
+                                    int dtype, mi355x_stream stream);
+
 /* rms_norm_image / fused_add_rms_norm_image: rms_norm (fused_add_rms_norm) whose normalised output is written
  * directly as the activation operand image of the prefill GEMM (the format mi355x_awq_gemm_silu_mul_packed
  * produces and mi355x_w4a16_gemm_prepacked / mi355x_awq_gemm_packed_a consume: [row tile of 16][k tile of 32]

@@ -128,3 +128,7 @@ def fused_add_rms_norm_image(x, residual, weight, eps):
 
 def paged_prefill_attention_image(*a, **k):
     return None
+
+
+def rotary_reshape_and_cache(*a, **k):
+    return False

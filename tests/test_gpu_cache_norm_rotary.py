@@ -561,3 +561,33 @@ def test_greedy_advance_nan_and_inf_rows():
         ops().greedy_advance(lg, tok, pos, seq, slots, bt, bs)
         assert tok.cpu().tolist() == [0, 777, 0, 500, 5]
         assert tok.cpu().tolist() == torch.argmax(lg.float().cpu(), dim=-1).tolist()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,KVH,D", [(100, 2, 128), (1024, 8, 128), (17, 1, 64)])
+def test_rotary_reshape_and_cache_is_bit_identical(dtype, T, KVH, D):
+    """MI355X-side prefill fusion: the key rows rotated on their way into the cache == rotary_embedding on the keys
+    followed by reshape_and_cache (both caches, bit for bit; padded slots skipped; the key tensor itself untouched)."""
+    g = torch.Generator().manual_seed(T + D)
+    d = dev()
+    BS, nb = 16, (T + 15) // 16 + 3
+    width = (4 * KVH + 2 * KVH) * D
+    qkv = (torch.randn(T, width, generator=g) * 0.7).to(dtype).to(d)
+    k = qkv[:, 4 * KVH * D:5 * KVH * D].view(T, KVH, D)            # strided views of a qkv row, as in the model
+    v = qkv[:, 5 * KVH * D:].view(T, KVH, D)
+    pos = torch.randint(0, 2048, (T,), generator=g).to(d)
+    cos_sin = torch.randn(2048, D, generator=g).to(dtype).to(d)
+    slots = torch.randperm(nb * BS, generator=g)[:T].to(torch.int64)
+    slots[T // 2] = -1
+    slots = slots.to(d)
+    kc = torch.zeros(nb, KVH, D // 8, BS, 8, dtype=dtype, device=d)
+    vc = torch.zeros(nb, KVH, D, BS, dtype=dtype, device=d)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    k_rot = k.clone()
+    ops().rotary_embedding(pos, k_rot.view(T, KVH * D), None, D, cos_sin, True)
+    ops().reshape_and_cache(k_rot, v, kc_ref, vc_ref, slots)
+    k_before = k.clone()
+    assert ops().rotary_reshape_and_cache(pos, k, v, kc, vc, slots, cos_sin)
+    assert_bit_exact(kc, kc_ref, "key cache")
+    assert_bit_exact(vc, vc_ref, "value cache")
+    assert_bit_exact(k, k_before, "key rows untouched")

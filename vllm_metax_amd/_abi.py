@@ -79,6 +79,7 @@ PROTOTYPES = {
     "mi355x_merge_attn_states": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mi355x_qkv_rope_cache": (
         _I, [_P, _L, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _L, _L, _I, _P]),
+    "mi355x_rotary_reshape_and_cache": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, _L, _I, _I, _I, _I, _I, _P]),
     "mi355x_paged_prefill_attention_image": (
         _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _I, _L, _L, _L, _I, _I, _P, _P, _P, _P, _P]),
     "mi355x_rms_norm_image": (_I, [_P, _P, _P, _F, _I, _I, _L, _I, _P]),

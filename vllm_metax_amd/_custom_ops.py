@@ -689,6 +689,29 @@ def awq_gemm_silu_mul(input: torch.Tensor, qweight: torch.Tensor, qzeros: torch.
     return out
 
 
+def rotary_reshape_and_cache(positions: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                             key_cache: torch.Tensor, value_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                             cos_sin_cache: torch.Tensor) -> bool:
+    """MI355X-side prefill fusion: rotary_embedding (NeoX, rot_dim == head_size) on the key rows + reshape_and_cache
+    in one launch; the rotated keys go only to the cache (`key` [T, KVH, D] is not modified).  False: not
+    applicable, nothing launched."""
+    _dev(positions, key, value, key_cache, value_cache, slot_mapping, cos_sin_cache)
+    if key.dtype not in (torch.bfloat16, torch.float16) or key_cache.dtype != key.dtype or key_cache.dim() != 5 \
+            or cos_sin_cache.dtype != key.dtype or cos_sin_cache.size(-1) != key.size(2) \
+            or not cos_sin_cache.is_contiguous():
+        return False
+    if positions.dtype != torch.int64 or slot_mapping.dtype != torch.int64:
+        raise RuntimeError("rotary_reshape_and_cache: positions and slot_mapping must be int64")
+    rc = _abi.load().mi355x_rotary_reshape_and_cache(
+        _ptr(key), _ptr(value), _ptr(key_cache), _ptr(value_cache), _ptr(slot_mapping), _ptr(positions),
+        _ptr(cos_sin_cache), slot_mapping.size(0), key.stride(0), value.stride(0), key.size(1), key.size(2),
+        key_cache.size(3), key_cache.size(4), _dt(key), _stream())
+    if rc == 1:
+        return False
+    _abi.check(rc, "rotary_reshape_and_cache")
+    return True
+
+
 def paged_prefill_attention_image(query: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
                                   num_kv_heads: int, scale: float, block_tables: torch.Tensor,
                                   seq_lens: torch.Tensor, cu_seqlens_q: torch.Tensor, max_query_len: int,

@@ -22,12 +22,15 @@ constexpr int kTokTile = 16;
 // ---------------------------------------------------------------------------
 // Tiled path: grid (ceil(T/16), num_heads), 256 threads.
 // Requires x == 16/sizeof(T), head_size % x == 0, 16-byte aligned rows.
-template <typename T>
+// ROPE (mi355x_rotary_reshape_and_cache): the key rows are rotated (NeoX, rot_dim == head_size, the arithmetic of
+// rotary_embedding) on their way into the cache; `key` itself is not modified.
+template <typename T, bool ROPE = false>
 __global__ __launch_bounds__(256) void reshape_and_cache_tiled_kernel(
     const T* __restrict__ key, const T* __restrict__ value, T* __restrict__ key_cache,
     T* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping,
     int num_tokens, int64_t key_stride, int64_t value_stride, int num_heads,
-    int head_size, int block_size) {
+    int head_size, int block_size, const int64_t* __restrict__ positions = nullptr,
+    const T* __restrict__ cos_sin_cache = nullptr) {
   constexpr int X = 16 / sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // V tile [kTokTile][head_size + X] (one 16-B pad per row), then slot tables.
@@ -61,11 +64,29 @@ __global__ __launch_bounds__(256) void reshape_and_cache_tiled_kernel(
     const int64_t blk = s_blk[j];
     if (blk < 0) continue;
     const int t = t0 + j;
+    if constexpr (ROPE) {
+      // a thread with c < chunks / 2 rotates the chunk pair (c, c + chunks / 2): elements d and d + head_size / 2
+      if (c < chunks / 2) {
+        const int half = chunks / 2;
+        const T* kp = key + t * key_stride + (int64_t)head * head_size;
+        Vec16<T> x = load16(kp + c * X);
+        Vec16<T> y = load16(kp + (c + half) * X);
+        const T* cs_row = cos_sin_cache + positions[t] * head_size;
+        const Vec16<T> cs = load16(cs_row + c * X);
+        const Vec16<T> sn = load16(cs_row + (c + half) * X);
+#pragma unroll
+        for (int e = 0; e < X; ++e) rot_pair<T>(x.e[e], y.e[e], cs.e[e], sn.e[e]);
+        T* kb = key_cache + ((blk * num_heads + head) * chunks * block_size + s_off[j]) * X;
+        store16(kb + (int64_t)c * block_size * X, x);
+        store16(kb + (int64_t)(c + half) * block_size * X, y);
+      }
+    } else {
     const uint4 kv = *reinterpret_cast<const uint4*>(key + t * key_stride +
                                                      (int64_t)head * head_size + c * X);
     T* kdst = key_cache +
               (((blk * num_heads + head) * chunks + c) * block_size + s_off[j]) * X;
     *reinterpret_cast<uint4*>(kdst) = kv;
+    }
     const uint4 vv = *reinterpret_cast<const uint4*>(value + t * value_stride +
                                                      (int64_t)head * head_size + c * X);
     *reinterpret_cast<uint4*>(vt + j * row + c * X) = vv;
@@ -381,6 +402,34 @@ int mi355x_reshape_and_cache(const void* key, const void* value, void* key_cache
                          value_stride, num_heads, head_size, block_size, x);
     }
     return check_launch("reshape_and_cache");
+  });
+}
+
+// returns 1 (no error) when the fused form does not apply: run rotary_embedding on the key rows, then reshape_and_cache
+int mi355x_rotary_reshape_and_cache(const void* key, const void* value, void* key_cache, void* value_cache,
+                                    const int64_t* slot_mapping, const int64_t* positions,
+                                    const void* cos_sin_cache, int num_tokens, int64_t key_stride,
+                                    int64_t value_stride, int num_heads, int head_size, int block_size, int x,
+                                    int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && num_heads > 0 && head_size > 0 && block_size > 0 && x > 0, MI355X_EINVAL,
+                 "rotary_reshape_and_cache: bad sizes");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(key && value && key_cache && value_cache && slot_mapping && positions && cos_sin_cache,
+                 MI355X_EINVAL, "rotary_reshape_and_cache: null pointer");
+  if (dtype != MI355X_BF16 && dtype != MI355X_F16) return 1;
+  if (x != 8 || head_size % 16 != 0 || key_stride % 8 != 0 || value_stride % 8 != 0 || !aligned16(key) ||
+      !aligned16(value) || !aligned16(key_cache) || !aligned16(cos_sin_cache))
+    return 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return MI355X_DISPATCH_HALF(dtype, [&] {
+    dim3 grid((num_tokens + kTokTile - 1) / kTokTile, num_heads);
+    size_t smem = (size_t)kTokTile * (head_size + 8) * sizeof(scalar_t) + kTokTile * (sizeof(int64_t) + sizeof(int));
+    hipLaunchKernelGGL((reshape_and_cache_tiled_kernel<scalar_t, true>), grid, dim3(256), smem, s,
+                       static_cast<const scalar_t*>(key), static_cast<const scalar_t*>(value),
+                       static_cast<scalar_t*>(key_cache), static_cast<scalar_t*>(value_cache), slot_mapping,
+                       num_tokens, key_stride, value_stride, num_heads, head_size, block_size, positions,
+                       static_cast<const scalar_t*>(cos_sin_cache));
+    return check_launch("rotary_reshape_and_cache");
   });
 }
 

@@ -364,14 +364,21 @@ class HotPathModel:
             q = qkv[:, :L.q_size]
             k = qkv[:, L.q_size:L.q_size + L.kv_size]
             v = qkv[:, L.q_size + L.kv_size:]
+            cached = False
             if getattr(self, "_pf_rope_q_in_attn", False) and not defer:
-                # prefill: the attention kernel rotates the query rows while it loads them; only k here
-                ops.rotary_embedding(positions, k, None, cfg.head_dim, self.cos_sin, True)
+                # prefill: the attention kernel rotates the query rows while it loads them; the key rows are
+                # rotated on their way into the cache (one launch), or in place when that form does not apply
+                cached = self.kv_dtype == "auto" and ops.rotary_reshape_and_cache(
+                    positions, k.view(-1, L.kv_heads, cfg.head_dim), v.view(-1, L.kv_heads, cfg.head_dim),
+                    self.k_cache[i], self.v_cache[i], slots, self.cos_sin)
+                if not cached:
+                    ops.rotary_embedding(positions, k, None, cfg.head_dim, self.cos_sin, True)
             else:
                 ops.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin, True)
-            ops.reshape_and_cache(k.view(-1, L.kv_heads, cfg.head_dim), v.view(-1, L.kv_heads, cfg.head_dim),
-                                  self.k_cache[i], self.v_cache[i], slots, self.kv_dtype, self.k_scale,
-                                  self.v_scale)
+            if not cached:
+                ops.reshape_and_cache(k.view(-1, L.kv_heads, cfg.head_dim), v.view(-1, L.kv_heads, cfg.head_dim),
+                                      self.k_cache[i], self.v_cache[i], slots, self.kv_dtype, self.k_scale,
+                                      self.v_scale)
         if attn is None:
             attn = attn_fn(i, q.view(-1, L.q_heads, cfg.head_dim))
         if fuse:
