@@ -46,6 +46,11 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 MFMA_8BIT_PEAK_TFLOPS = 5000.0  # dense fp8 / int8 MFMA peak (the --quant fp8 / int8 GEMMs)
+# model -> (harness.ModelConfig constructor, BASELINE.json's weight format, label)
+MODELS = {"llama-3-8b": ("llama3_8b", "awq", "Llama-3-8B AWQ-int4"),
+          "llama-3-70b": ("llama3_70b", "fp8", "Llama-3-70B FP8"),
+          "qwen2-72b": ("qwen2_72b", "gptq", "Qwen2-72B GPTQ-int4"),
+          "tiny": ("tiny", "awq", "tiny test model")}
 WEIGHT_FORMAT = {"awq": "w4a16 g128", "gptq": "w4a16 g128", "fp8": "w8a8 fp8", "int8": "w8a8 int8",
                  "none": "bf16"}
 
@@ -55,8 +60,25 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--quant", default="awq", choices=["awq", "gptq", "fp8", "int8", "none"])
-    ap.add_argument("--model", default="llama-3-8b", choices=["llama-3-8b", "tiny"])
+    ap.add_argument("--quant", default=None, choices=["awq", "gptq", "fp8", "int8", "none"],
+                    help="weight format; default: the one BASELINE.json names for the model (llama-3-8b: awq, "
+                         "llama-3-70b: fp8, qwen2-72b: gptq)")
+    ap.add_argument("--model", default="llama-3-8b", choices=sorted(MODELS),
+                    help="llama-3-70b / qwen2-72b are BASELINE's TP=8 models: run them with --gpus 8, or rehearse "
+                         "ONE rank's shard on one GPU with --tp-rank-of 8")
+    ap.add_argument("--tp-rank-of", type=int, default=0, metavar="N",
+                    help="single-GPU rehearsal of ONE rank of a TP=N group: builds rank --tp-rank's shard (heads, FFN "
+                         "columns, vocabulary slice of 1/N), issues every RCCL collective on a 1-rank group (captured "
+                         "in the decode graph) and reports that rank's job time; no peer traffic is measured")
+    ap.add_argument("--tp-rank", type=int, default=0)
+    ap.add_argument("--layers", type=int, default=0, help="override the layer count (rehearsals / tests only; "
+                                                           "the line then says so and is not a BASELINE number)")
+    ap.add_argument("--no-plugin-surface", action="store_true",
+                    help="skip the extra measurement of the same job through the plain vLLM-reachable op surface "
+                         "(the \"plugin_surface\" object; N = 1 only)")
+    ap.add_argument("--no-tp8-extra", action="store_true",
+                    help="--gpus 8 with the default model: skip the extra Llama-3-70B FP8 TP=8 job "
+                         "(the \"baseline_tp8_model\" object)")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--input-len", type=int, default=1024)
     ap.add_argument("--output-len", type=int, default=128)
@@ -84,8 +106,12 @@ class EventTimer:
     def __init__(self):
         self.records = []
         self.enabled = False
+        self.collect = None      # a list: record (name, flops, bytes, closure) of every launch instead of timing it
 
     def time(self, name, flops, nbytes, fn):
+        if self.collect is not None:
+            self.collect.append((name, flops, nbytes, fn))
+            return fn()
         if not self.enabled:
             return fn()
         a = torch.cuda.Event(enable_timing=True)
@@ -95,6 +121,12 @@ class EventTimer:
         b.record()
         self.records.append((name, flops, nbytes, a, b))
         return out
+
+    def discard_last(self, name):
+        """The call just wrapped reported "not applicable" (nothing was launched): drop its record."""
+        lst = self.collect if self.collect is not None else (self.records if self.enabled else None)
+        if lst and lst[-1][0] == name:
+            lst.pop()
 
     def summary(self):
         agg = {}
@@ -134,8 +166,8 @@ def instrument(model, timer: EventTimer):
         nbytes = self.weight_bytes() + 2.0 * m * self.k + 1.0 * m * self.n
         name = f"{self.quant}_gemm_{'large' if m >= 128 else 'small'}_m"
         out = timer.time(name, flops, nbytes, lambda: orig_silu(self, x))
-        if out is None and timer.enabled and timer.records and timer.records[-1][0] == name:
-            timer.records.pop()          # fused path not taken: the caller times the plain GEMM
+        if out is None:
+            timer.discard_last(name)     # fused path not taken: the caller times the plain GEMM
         return out
 
     def timed_deferred(self, x):
@@ -158,9 +190,8 @@ def instrument(model, timer: EventTimer):
         def w(*a, **k):
             flops, nbytes = cost(*a, **k)
             out = timer.time(name, flops, nbytes, lambda: fn(*a, **k))
-            if record_as and (out is None or out is False) and timer.enabled and timer.records \
-                    and timer.records[-1][0] == name:
-                timer.records.pop()
+            if record_as and (out is None or out is False):
+                timer.discard_last(name)
             return out
         setattr(ops, opname, w)
         if opname == "paged_attention_fused_qkv":
@@ -334,38 +365,67 @@ def cpu_baseline(args, cfg):
     }
 
 
-def spawn_ranks(n: int) -> int:
+def spawn_ranks(n: int, limit_s: float = 3000.0) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (the
-    parent never touches the GPU), relay rank 0's JSON line, return the worst exit code."""
+    parent never touches the GPU), relay rank 0's JSON line, return the worst exit code.  Every child is
+    polled: when one exits non-zero (OOM, import error, RCCL init) or the wall-clock limit passes, the others
+    are terminated instead of waiting forever in a rendezvous or a collective."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
-    return max(abs(rc) for rc in rcs)
+    s.close()          # (released before the children bind it: a lost race shows up as a failed rendezvous -> non-zero)
+    procs, rc = [], 0
+    out_f = tempfile.TemporaryFile(mode="w+")
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out_f if r == 0 else subprocess.DEVNULL))
+        t0 = time.time()
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                rc = max(abs(c) for c in codes)
+                break
+            failed = [i for i, c in enumerate(codes) if c not in (None, 0)]
+            if failed or time.time() - t0 > limit_s:
+                why = f"rank {failed[0]} exited with {codes[failed[0]]}" if failed else f"no result after {limit_s:.0f} s"
+                print(f"bench.py: {why}: stopping the other ranks", file=sys.stderr)
+                rc = max([abs(codes[i]) for i in failed] + [1])
+                break
+            time.sleep(0.5)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:  # noqa: BLE001
+                p.kill()
+    out_f.seek(0)
+    sys.stdout.write(out_f.read())
+    sys.stdout.flush()
+    return rc
 
 
-def timed_jobs(model, tokens, args, world, barrier, timer=None):
+def timed_jobs(model, tokens, args, world, barrier, timer=None, steps=None, warmup=None):
     """W warm-up jobs (at least one: it builds the decode graph), then EXACTLY K timed jobs bracketed by
     barrier + synchronize; returns (max-over-ranks seconds, ttft samples)."""
-    for _ in range(max(args.warmup, 1)):
+    steps = args.steps if steps is None else steps
+    for _ in range(max(args.warmup if warmup is None else warmup, 1)):
         run_job(model, tokens, args)
     barrier()
     if timer is not None:
         timer.enabled = True
     ttft_events, start_ev = [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         s = torch.cuda.Event(enable_timing=True)
         s.record()
         tt = []
@@ -374,11 +434,147 @@ def timed_jobs(model, tokens, args, world, barrier, timer=None):
         ttft_events.append(tt)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, model.device, world)
+    if timer is not None:
+        timer.enabled = False
     ttfts = []
     for s, tt in zip(start_ev, ttft_events):
         for n, ev in tt:
             ttfts += [s.elapsed_time(ev)] * n
     return elapsed, ttfts
+
+
+def check_outputs(model, what: str) -> None:
+    """A job whose logits are non-finite or degenerate is not a measurement (round 2's --quant fp8 records were
+    taken on such a job): fail loudly instead of printing a number."""
+    for name in ("last_prefill_logits", "last_logits"):
+        lg = getattr(model, name, None)
+        if lg is None:
+            continue
+        lg = lg.float()
+        if not bool(torch.isfinite(lg).all()) or float(lg.abs().max()) == 0.0:
+            raise SystemExit(f"bench.py: {what}: {name} are non-finite or all zero — the job computed garbage, "
+                             f"no number is reported")
+    tok = model.d_tokens
+    if int(tok.min()) < 0 or int(tok.max()) >= model.cfg.vocab:
+        raise SystemExit(f"bench.py: {what}: sampled tokens outside the vocabulary")
+
+
+def decode_kernel_times(model, timer: EventTimer, args, reps: int = 3):
+    """Graph-consistent timings of the decode step's kernels.  One eager decode step is run with the timer in
+    collect mode (it records every wrapped launch as a closure over that step's real tensors); then, per kernel
+    name, ALL its launches of the step (one per layer and projection: 32-128 launches over different weights /
+    KV caches, > 256 MiB in total, so nothing is served from the Infinity Cache that would not be in the real
+    step) are captured into one HIP graph and replayed `reps` times between two HIP events.  The eager bracket
+    the earlier rounds used put ~13 us of launch latency inside each decode GEMM's events."""
+    mid = args.input_len + (args.output_len - 1) // 2
+    model.set_decode_lengths(torch.full((args.batch,), mid, device=model.device))
+    model.mean_decode_len_for_cost = mid + 1
+    saved = (model.d_tokens.clone(), model.d_positions.clone(), model.d_seq_lens.clone(), model.d_slots.clone())
+    timer.collect = []
+    model.decode_step(use_graph=False)
+    torch.cuda.synchronize()
+    calls, timer.collect = timer.collect, None
+    groups = {}
+    for name, flops, nbytes, fn in calls:
+        groups.setdefault(name, []).append((flops, nbytes, fn))
+    out = {}
+    for name, items in groups.items():
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _, _, fn in items:
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _, _, fn in items:
+                    fn()
+            g.replay()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            n = len(items) * reps
+            out[name] = {"launches": n, "ms": a.elapsed_time(b), "steps_timed": reps,
+                         "flops": sum(i[0] for i in items) * reps,
+                         "bytes": sum(i[1] for i in items) * reps,
+                         "timing": f"HIP-graph replay of the {len(items)} launches of one decode step, x{reps}"}
+            del g
+        except Exception as e:  # noqa: BLE001 - an op that cannot be captured keeps no entry
+            print(f"bench.py: decode kernel timing of {name} failed: {e!r}", file=sys.stderr)
+            torch.cuda.synchronize()
+    for dst, src in zip((model.d_tokens, model.d_positions, model.d_seq_lens, model.d_slots), saved):
+        dst.copy_(src)
+    return out
+
+
+def no_prepack_entry(model, args, timer: EventTimer):
+    """The prefill w4a16 GEMM WITHOUT the load-time weight image (int4 words dequantised inside every call):
+    the four projections of layer 0 at the chunk size, 3 calls each, HIP events — reported beside the headline's
+    image-based GEMM so that the line shows what the image buys."""
+    from vllm_metax_amd import _custom_ops as ops
+    L = model.layers[0]
+    m = args.chunk_seqs * args.input_len
+    tot_ms, tot_flops, n = 0.0, 0.0, 0
+    for q in (L.qkv, L.o, L.gate_up, L.down):
+        if q.quant not in ("awq", "gptq"):
+            return None
+        x = (torch.randn(m, q.k, device=model.device) * 0.5).to(model.dtype)
+
+        def call():
+            if q.quant == "awq":
+                return ops.awq_gemm(x, q.qweight, q.qzeros, q.scales, 8, torch.empty(0), x.dtype == torch.bfloat16)
+            return ops.gptq_gemm(x, q.qweight, q.qzeros, q.scales, q.g_idx, True, 4, q.group, torch.empty(0),
+                                 torch.empty(0), x.dtype == torch.bfloat16)
+        call()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(3):
+            call()
+        b.record()
+        torch.cuda.synchronize()
+        tot_ms += a.elapsed_time(b)
+        tot_flops += 3 * 2.0 * m * q.n * q.k
+        n += 3
+    ach = tot_flops / (tot_ms * 1e-3) / 1e12
+    return {"kernel": "awq_gemm_large_m_no_prepack", "bound": "mfma", "achieved": round(ach, 2),
+            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            "frac_fp8_peak": round(ach / MFMA_8BIT_PEAK_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(tot_ms / n * 1e3, 2), "launches": n, "total_ms": round(tot_ms, 2),
+            "note": "the same four layer-0 GEMMs at the chunk size through awq_gemm / gptq_gemm (weights dequantised "
+                    "per call: dequant-pack + activation pack + MFMA kernel), measured after the timed region"}
+
+
+def hbm_weights_gb(model) -> dict:
+    """Bytes the model keeps resident in HBM, by kind (GB = 1e9 B)."""
+    w = img = 0
+    for L in model.layers:
+        for q in (L.qkv, L.o, L.gate_up, L.down):
+            w += q.weight_bytes()
+            im = getattr(q, "_image", None)
+            if im is not None:
+                img += im.numel() * im.element_size()
+    other = (model.embed.numel() + model.lm_head.numel()) * model.embed.element_size()
+    return {"quantized_weights": round(w / 1e9, 3), "prefill_weight_images": round(img / 1e9, 3),
+            "embed_lm_head": round(other / 1e9, 3), "total": round((w + img + other) / 1e9, 3)}
+
+
+def make_cfg(args, tp_degree, rank, model_name=None, quant=None):
+    from vllm_metax_amd import harness
+    name = model_name or args.model
+    ctor, default_quant, _ = MODELS[name]
+    q = quant or args.quant or default_quant
+    cfg = getattr(harness.ModelConfig, ctor)(q)
+    cfg.tp, cfg.tp_rank = tp_degree, (rank if tp_degree > 1 else 0)
+    cfg.kv_cache_dtype = args.kv_cache_dtype
+    if args.layers:
+        cfg.layers = args.layers
+    return cfg
 
 
 def main():
@@ -392,6 +588,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}), "
                          f"or run bench.py --gpus N without a launcher")
+    if args.tp_rank_of and world != 1:
+        raise SystemExit("--tp-rank-of is a single-GPU rehearsal: use it with --gpus 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # rehearsal on a 1-GPU box: BENCH_DIST_BACKEND=gloo BENCH_SHARE_GPU0=1 runs N ranks on cuda:0
@@ -400,9 +598,17 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     group = None
-    if world > 1:
+    if world > 1 or args.tp_rank_of:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
+        if args.tp_rank_of:      # a 1-rank RCCL group: every collective is issued (and captured), nothing travels
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            torch.distributed.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                                 device_id=torch.device("cuda", local_rank))
+        elif backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             torch.distributed.init_process_group(backend)
@@ -410,18 +616,14 @@ def main():
 
     from vllm_metax_amd import harness
     parallelism = args.parallelism or ("tp" if world > 1 else "dp")
-    tp = world if parallelism == "tp" else 1
-
-    def make_cfg(tp_degree):
-        cfg = harness.ModelConfig.llama3_8b(args.quant) if args.model == "llama-3-8b" \
-            else harness.ModelConfig.tiny(args.quant)
-        cfg.tp, cfg.tp_rank = tp_degree, (rank if tp_degree > 1 else 0)
-        cfg.kv_cache_dtype = args.kv_cache_dtype
-        return cfg
-    cfg = make_cfg(tp)
+    tp = args.tp_rank_of or (world if parallelism == "tp" else 1)
+    cfg = make_cfg(args, tp, args.tp_rank if args.tp_rank_of else rank)
+    quant = cfg.quant
     max_len = args.input_len + args.output_len
     model = harness.HotPathModel(cfg, args.batch, max_len, device=f"cuda:{local_rank}", seed=0,
                                  tp_group=group if tp > 1 else None)
+    if args.tp_rank_of:
+        model.collectives_always = True
     model.setup_decode(args.batch, args.input_len, max_len)
     model.cfg_ctx_for_cost = 0
     model.mean_decode_len_for_cost = args.input_len + (args.output_len - 1) / 2.0 + 1
@@ -433,28 +635,29 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # every hot op is wrapped so that a launch CAN be bracketed by HIP events; the timer is
-    # off during warm-up / graph capture and on inside the timed region, where it sees the
-    # eagerly launched kernels (all of prefill); graph-replayed decode launches are timed
-    # afterwards by a few eager decode steps on the same stream.
+    # every hot op is wrapped so that a launch CAN be bracketed by HIP events; the timer is off during warm-up /
+    # graph capture and on inside the timed region, where it sees the eagerly launched kernels (all of prefill);
+    # the graph-replayed decode launches are timed afterwards, again from HIP graphs (decode_kernel_times).
     timer = EventTimer()
     instrument(model, timer)
     # ---- timed region: exactly K jobs -------------------------------------------------
     elapsed, ttfts = timed_jobs(model, tokens, args, world, barrier, timer)
     ttft_p50 = statistics.median(ttfts) if ttfts else None
+    check_outputs(model, f"{cfg.name} {quant}")
+    graph_ok, graph_err = model._graph not in (None, False), model.graph_error
+    weights_gb = hbm_weights_gb(model)
 
-    # ---- decode kernels: 8 eager decode steps at the mean decode context, bracketed ----------
-    mid = args.input_len + (args.output_len - 1) // 2
-    model.set_decode_lengths(torch.full((args.batch,), mid, device=model.device))
-    model.mean_decode_len_for_cost = mid + 1 + 3.5
-    for _ in range(8):
-        model.decode_step(use_graph=False)
-    torch.cuda.synchronize()
-    timer.enabled = False
     agg = timer.summary()
+    dec = decode_kernel_times(model, timer, args)
+    dec_named = {}
+    for name, d in dec.items():  # decode launches: graph-consistent timings, beside the prefill-side entries
+        final = name if name not in agg else name + "_decode"
+        agg[final] = d
+        dec_named[final] = d
 
     def roof(name, d):
         avg_ms = d["ms"] / d["launches"]
+        extra = {"timing": d["timing"]} if "timing" in d else {}
         if d["flops"] > 0 and name.endswith("large_m") or name == "paged_prefill_attention":
             ach = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
             peak = MFMA_8BIT_PEAK_TFLOPS if name.startswith(("fp8_gemm", "int8_gemm")) \
@@ -463,7 +666,7 @@ def main():
                  "peak": peak, "unit": "TFLOP/s",
                  "frac": round(ach / peak, 4), "traffic": None,
                  "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
-                 "total_ms": round(d["ms"], 2)}
+                 "total_ms": round(d["ms"], 2), **extra}
             if name.endswith("gemm_large_m"):
                 # north_star words its GEMM target against the fp8 MFMA peak (5 PFLOP/s dense); the
                 # w4a16 GEMM multiplies bf16 operands, so `frac` is against the bf16 peak and this
@@ -474,30 +677,50 @@ def main():
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "launches": d["launches"],
-                "total_ms": round(d["ms"], 2)}
+                "total_ms": round(d["ms"], 2), **extra}
 
-    roofs = sorted((roof(n, d) for n, d in agg.items()), key=lambda r: -r["total_ms"])
+    # ranking by the share of the JOB: a prefill kernel's events cover the K timed jobs, a decode kernel's graph
+    # timing covers `reps` steps — scale the latter to the decode steps of the K jobs before sorting
+    def job_ms(name, d):
+        if name in dec_named:
+            return d["ms"] / d["steps_timed"] * (args.output_len - 1) * args.steps
+        return d["ms"]
+    roofs = []
+    for n_, d in agg.items():
+        r = roof(n_, d)
+        r["job_share"] = round(job_ms(n_, d) / (elapsed * 1e3), 4)
+        roofs.append(r)
+    roofs.sort(key=lambda r: -r["job_share"])
     # HBM-side bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of
     # the same kernels at the same shapes; a counter pass cannot run inside the timed region)
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
-    if os.path.exists(tpath) and args.model == "llama-3-8b" and tp == 1 and args.kv_cache_dtype == "auto":
+    here = os.path.dirname(os.path.abspath(__file__))
+    tpath = next((pth for pth in (os.path.join(here, "profiles", f) for f in ("r03_pmc_traffic.json",
+                                                                              "r02_pmc_traffic.json"))
+                  if os.path.exists(pth)), None)
+    if tpath and args.model == "llama-3-8b" and tp == 1 and args.kv_cache_dtype == "auto" and quant == "awq":
         with open(tpath) as f:
             traffic = json.load(f)
         for r in roofs:
             if r["kernel"] in traffic:
                 r["traffic"] = traffic[r["kernel"]]
-                r["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_summary.txt)"
+                r["traffic_unit"] = f"bytes per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/{os.path.basename(tpath)})"
+    if quant in ("awq", "gptq") and harness.QLinear.prepack and world == 1 and not args.tp_rank_of:
+        try:
+            e = no_prepack_entry(model, args, timer)
+            if e is not None:
+                roofs.append(e)
+        except Exception as ex:  # noqa: BLE001
+            print(f"bench.py: no-prepack entry failed: {ex!r}", file=sys.stderr)
     if args.kernel_stats and rank == 0:
         for r in roofs:
             print(json.dumps(r), file=sys.stderr)
 
     # ---- tp runs: the collective-free alternative (one replica per GPU) measured in the same run ----
     dp_extra = None
-    if tp > 1 and not args.no_dp_extra:
-        graph_ok, graph_err = model._graph not in (None, False), model.graph_error
+    if tp > 1 and world > 1 and not args.no_dp_extra and args.model == "llama-3-8b":
         del model
         torch.cuda.empty_cache()
-        rep_model = harness.HotPathModel(make_cfg(1), args.batch, max_len, device=f"cuda:{local_rank}", seed=0)
+        rep_model = harness.HotPathModel(make_cfg(args, 1, 0), args.batch, max_len, device=f"cuda:{local_rank}", seed=0)
         rep_model.setup_decode(args.batch, args.input_len, max_len)
         rep_model.cfg_ctx_for_cost = 0
         rep_model.mean_decode_len_for_cost = args.input_len + (args.output_len - 1) / 2.0 + 1
@@ -506,8 +729,58 @@ def main():
                     "unit": "output tokens/s", "scaling": "weak", "ms_per_step": round(dp_elapsed / args.steps * 1e3, 3),
                     "global_batch": args.batch * world,
                     "note": "one model replica per GPU, each serving its own batch: no data-path collective"}
-    else:
-        graph_ok, graph_err = model._graph not in (None, False), model.graph_error
+        del rep_model
+        model = None
+
+    # ---- --gpus 8, default model: BASELINE's TP=8 headline model (Llama-3-70B FP8) in the same run ----
+    tp8_extra = None
+    if world == 8 and tp == 8 and args.model == "llama-3-8b" and not args.no_tp8_extra:
+        model = None
+        torch.cuda.empty_cache()
+        try:
+            c70 = make_cfg(args, 8, rank, model_name="llama-3-70b", quant="fp8")
+            m70 = harness.HotPathModel(c70, args.batch, max_len, device=f"cuda:{local_rank}", seed=0, tp_group=group)
+            m70.setup_decode(args.batch, args.input_len, max_len)
+            m70.cfg_ctx_for_cost = 0
+            m70.mean_decode_len_for_cost = args.input_len + (args.output_len - 1) / 2.0 + 1
+            t70 = torch.randint(0, c70.vocab, (args.batch, args.input_len), device=m70.device, generator=gen)
+            k70 = min(args.steps, 3)
+            e70, tt70 = timed_jobs(m70, t70, args, world, barrier, steps=k70, warmup=1)
+            check_outputs(m70, "llama-3-70b fp8 tp8")
+            tp8_extra = {"model": "Llama-3-70B FP8 (w8a8 fp8, per-channel weight scales), TP=8", "steps": k70,
+                         "value": round(k70 * args.batch * args.output_len / e70, 2), "unit": "output tokens/s",
+                         "ms_per_step": round(e70 / k70 * 1e3, 3),
+                         "ttft_p50_ms": round(statistics.median(tt70), 2) if tt70 else None,
+                         "decode_graph": m70._graph not in (None, False), "hbm_weights_gb_per_rank": hbm_weights_gb(m70)}
+            del m70
+        except Exception as ex:  # noqa: BLE001 - the scaling line must survive a failure of the extra job
+            tp8_extra = {"model": "Llama-3-70B FP8, TP=8", "error": repr(ex)}
+
+    # ---- N = 1: the same job through the plain op surface upstream vLLM reaches (no cross-op fusion) ----
+    surface = None
+    if world == 1 and not args.tp_rank_of and not args.no_plugin_surface:
+        model = None
+        torch.cuda.empty_cache()
+        try:
+            sm = harness.PluginSurfaceModel(make_cfg(args, 1, 0), args.batch, max_len, device=f"cuda:{local_rank}",
+                                            seed=0)
+            sm.setup_decode(args.batch, args.input_len, max_len)
+            sm.cfg_ctx_for_cost = 0
+            sm.mean_decode_len_for_cost = args.input_len + (args.output_len - 1) / 2.0 + 1
+            ks = min(args.steps, 3)
+            se, stt = timed_jobs(sm, tokens, args, world, barrier, steps=ks, warmup=1)
+            check_outputs(sm, "plugin surface")
+            surface = {"value": round(ks * args.batch * args.output_len / se, 2), "unit": "output tokens/s",
+                       "steps": ks, "ms_per_step": round(se / ks * 1e3, 3),
+                       "ttft_p50_ms": round(statistics.median(stt), 2) if stt else None,
+                       "decode_graph": sm._graph not in (None, False),
+                       "path": "quant_config.linear.apply_awq/apply_gptq (= torch.ops.vllm._apply_*), "
+                               "attention.backend.build_metadata + paged_attention_forward, torch.ops._C.{rms_norm, "
+                               "fused_add_rms_norm, rotary_embedding, silu_and_mul}, torch argmax; no operand images, "
+                               "no fused epilogues / prologues, MI355X_PREPACK_WEIGHTS off (the plugin's default)"}
+            del sm
+        except Exception as ex:  # noqa: BLE001
+            surface = {"error": repr(ex)}
 
     if rank != 0:
         if world > 1:
@@ -516,8 +789,15 @@ def main():
         return
     replicas = world if tp == 1 else 1       # dp: every rank served its own batch
     out_tokens = whole_job_tokens(args.steps, args.batch, args.output_len, world, tp)
+    label = MODELS[args.model][2]
+    if args.quant and args.quant != MODELS[args.model][1]:
+        label = f"{label.split()[0]} {WEIGHT_FORMAT.get(quant, quant)}"
+    image_on = bool(quant in ("awq", "gptq") and harness.QLinear.prepack and weights_gb["prefill_weight_images"] > 0)
+    par = f"tp{world}" if (tp > 1 and not args.tp_rank_of) else f"dp{world}"
+    if args.tp_rank_of:
+        par = f"rank {args.tp_rank} of tp{tp}, rehearsed on one GPU"
     result = {
-        "metric": "output tokens/sec (Llama-3-8B AWQ-int4, batch 64, 1024-in/128-out) + p50 TTFT",
+        "metric": f"output tokens/sec ({label}, batch {args.batch}, {args.input_len}-in/{args.output_len}-out) + p50 TTFT",
         "value": round(out_tokens / elapsed, 2),
         "unit": "output tokens/s",
         "n_gpus": world,
@@ -525,37 +805,53 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak" if tp == 1 else "strong",
+        "scaling": "weak" if (tp == 1 or args.tp_rank_of) else "strong",
         "vs_baseline": None,
-        "dtype": {"fp8": "fp8", "int8": "int8"}.get(args.quant, "bf16"),
+        "dtype": {"fp8": "fp8", "int8": "int8"}.get(quant, "bf16"),
         "data": "synthetic",
-        "config": {"workload": f"{cfg.name}-{args.quant} {WEIGHT_FORMAT.get(args.quant, args.quant)}: prefill {args.batch}x{args.input_len} "
+        "config": {"workload": f"{cfg.name}-{quant} {WEIGHT_FORMAT.get(quant, quant)}: prefill {args.batch}x{args.input_len} "
                                f"in chunks of {args.chunk_seqs} seqs + {args.output_len - 1} graph-replayed "
                                f"decode steps (1 step = 1 whole job)",
                    "batch": args.batch, "global_batch": args.batch * replicas,
                    "input_len": args.input_len, "output_len": args.output_len,
-                   "parallelism": f"tp{world}" if tp > 1 else f"dp{world}", "kv_block_size": 16,
+                   "parallelism": par, "kv_block_size": 16,
                    "kv_cache_dtype": args.kv_cache_dtype,
+                   "layers": cfg.layers,
+                   "prefill_weight_image": ("bf16 operand image of the int4 weights, dequantised once at load "
+                                            "(MI355X_PREPACK=1): the prefill GEMM multiplies bf16 x bf16, decode "
+                                            "streams the int4 words" if image_on else "none"),
+                   "hbm_weights_gb": weights_gb,
+                   "outputs_finite": True,
                    "decode_graph": bool(graph_ok) and not args.no_graph,
-                   "collectives": ("RCCL all-reduce x2 per layer + all-gather of the logits, captured in the "
-                                   "decode graph" if tp > 1 else "none on the data path")},
+                   "collectives": ("none on the data path" if tp == 1 else
+                                   "RCCL all-reduce x2 per layer + all-gather of the logits, "
+                                   + ("captured in the decode graph" if graph_ok and not args.no_graph
+                                      else "issued eagerly (decode graph not captured)")
+                                   + (" — on a 1-rank group: issued, nothing travels" if args.tp_rank_of else ""))},
         "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
         "roofline": roofs[0] if roofs else None,
         "roofline_other": roofs[1:],
     }
+    if args.layers:
+        result["config"]["note"] = f"layer count overridden to {args.layers}: not a BASELINE configuration"
     if graph_err:
         result["config"]["decode_graph_error"] = graph_err
     if dp_extra is not None:
         result["dp_replicas"] = dp_extra
-    if world == 1 and not args.skip_cpu:
+    if tp8_extra is not None:
+        result["baseline_tp8_model"] = tp8_extra
+    if surface is not None:
+        result["plugin_surface"] = surface
+    if world == 1 and not args.skip_cpu and not args.tp_rank_of:
         try:
             result["cpu_baseline"] = cpu_baseline(args, cfg)
         except Exception as e:  # the baseline must never take the GPU number down with it
             result["cpu_baseline"] = {"value": None, "unit": "output tokens/s", "cores": 0,
                                       "kind": "port", "sample": f"failed: {e!r}"}
     print(json.dumps(result), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
+    if world > 1 or args.tp_rank_of:
+        if world > 1:
+            torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

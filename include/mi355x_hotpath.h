@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 3   /* 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive) */
+#define MI355X_ABI_VERSION 3   /* 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
+                                * 2 was BREAKING (kv_cache_dtype / k_scale / v_scale inserted before `stream` in reshape_and_cache*,
+                                * paged_attention_v1/_v2, paged_prefill_attention): a binding must refuse a library whose
+                                * mi355x_abi_version() differs from the version it was written for (vllm_metax_amd/_abi.py does) */
 
 typedef enum {
   MI355X_F16 = 0,  /* IEEE half  (torch.float16)  */
@@ -394,7 +397,7 @@ int mi355x_merge_attn_states(void* output, float* output_lse, const void* prefix
  * scaled_mm_int8: the int8 branch of cutlass_scaled_mm — out[M,N] (bf16/f16) =
  *   a_scales . (a[M,K] int8 row-major x b[K,N] int8 COLUMN-major) . b_scales (+ bias[N]), exact
  *   int32 accumulation, epilogue a_s * (b_s * float(acc)) + bias in fp32, one rounding.
- *   Arguments as mi355x_scaled_mm_fp8 (workspace: m*n 4-byte elements for the M <= 64 split-K).
+ *   Arguments as mi355x_scaled_mm_fp8 (workspace: sk*m*n 4-byte elements for an sk-way M <= 64 split-K).
  * ref: csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu:34-39, :84-140; schema
  *      csrc/torch_bindings.cpp:251-256.
  * static / dynamic_scaled_int8_quant: q = clamp(rint(x / scale), -127, 127); dynamic computes
@@ -503,8 +506,9 @@ int mi355x_greedy_advance(const void* logits, int64_t logits_stride, int num_seq
  * out[M,N] (bf16/f16) = (a_scales . a[M,K] e4m3fn row-major) x
  *                       (b_scales . b[K,N] e4m3fn COLUMN-major, ldb = b.stride(1))
  *                       (+ bias[N]).  a_scales: 1 or M floats; b_scales: 1 or N.
- * `workspace` (4-byte elements, 16-byte aligned, may be NULL): M <= 64: >= m*n lets the small-M
- * kernel split K across workgroups (zero-filled by the call); M >= 1024: >= (roundup(m,16) +
+ * `workspace` (4-byte elements, 16-byte aligned, may be NULL): M <= 64: sk*m*n elements let the small-M
+ * kernel split K across sk <= 8 workgroups (one partial slab [m, n] each, summed in slab order by a finish
+ * kernel: no memset, no atomics — deterministic and HIP-graph-replayable; contents are scratch); M >= 1024: >= (roundup(m,16) +
  * roundup(n,16)) * k bytes selects the prefill kernel (operands re-tiled into MFMA operand images,
  * LDS-DMA ring); otherwise the direct kernels run.
  * New capability behind the reference schema cutlass_scaled_mm

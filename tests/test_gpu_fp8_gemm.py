@@ -84,3 +84,60 @@ def test_scaled_mm_fp8_errors():
     with pytest.raises(RuntimeError):                        # mixed operand types
         ops().cutlass_scaled_mm(out, a, bi, s, s, None)
     assert ops().cutlass_scaled_mm_supports_fp8(90) is True
+
+
+# ------------------------------------------------------------------ the Llama-3-8B bench shapes
+BENCH_KN = [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)]
+
+
+def _sample_rows(m, gen):
+    """One random row of every 256-row block (the prefill kernel's M tile) + the corners."""
+    rows = {0, 1, m - 2, m - 1} if m > 2 else set(range(m))
+    for b0 in range(0, m, 256):
+        rows.add(b0 + int(torch.randint(0, min(256, m - b0), (1,), generator=gen)))
+    return torch.tensor(sorted(rows))
+
+
+@pytest.mark.parametrize("m", [64, 8192])
+@pytest.mark.parametrize("k,n", BENCH_KN)
+@pytest.mark.parametrize("kind", ["fp8", "int8"])
+def test_scaled_mm_llama8b_bench_shapes(kind, k, n, m):
+    """The (K, N) of the four Llama-3-8B projections at the decode (M = 64) and chunked-prefill (M = 8192) sizes
+    `bench.py --quant fp8 / int8` runs.  The whole output must be finite; the rows of a sample that touches every
+    256-row tile are checked against the oracle (an output row depends on its own A row only, so the sample is an
+    exact check of those rows: one ulp + 2e-4 max|ref| for fp8, bit-exact for int8), and every column tile is
+    covered by each sampled row."""
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(k + n + m)
+    if kind == "fp8":
+        a = (torch.randn(m, k, device=d, generator=g) * 2).clamp_(-448, 448).to(FP8)
+        b_nk = (torch.randn(n, k, device=d, generator=g) * 2).clamp_(-448, 448).to(FP8)
+        a_s = torch.rand(m, 1, device=d, generator=g) * 9e-3 + 1e-3
+        b_s = torch.rand(1, n, device=d, generator=g) * 9e-3 + 1e-3
+    else:
+        a = torch.randint(-127, 128, (m, k), device=d, generator=g, dtype=torch.int32).to(torch.int8)
+        b_nk = torch.randint(-127, 128, (n, k), device=d, generator=g, dtype=torch.int32).to(torch.int8)
+        a_s = torch.rand(m, 1, device=d, generator=g) * 1e-4 + 1e-5
+        b_s = torch.rand(1, n, device=d, generator=g) * 1e-2 + 1e-3
+    out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=d)
+    ops().cutlass_scaled_mm(out, a, b_nk.t(), a_s, b_s, None)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()), f"{kind} {m}x{n}x{k}: non-finite outputs"
+    rows = _sample_rows(m, torch.Generator().manual_seed(1))
+    a_c, as_c = a[rows.to(d)].cpu(), a_s[rows.to(d)].cpu()
+    b_c = b_nk.cpu().t()
+    got = out[rows.to(d)].cpu()
+    if kind == "fp8":
+        ref = R.scaled_mm_fp8(a_c, b_c, as_c, b_s.cpu(), torch.bfloat16)
+        assert_gemm_close(got, ref, f"fp8 bench shape {m}x{n}x{k}", max_frac=0.12)
+    else:
+        from tests.util import assert_bit_exact
+        ref = R.scaled_mm_int8(a_c, b_c, as_c, b_s.cpu(), torch.bfloat16)
+        assert_bit_exact(got, ref, f"int8 bench shape {m}x{n}x{k}")
+    # a second call on the same operands gives the same bits (workspace reuse, split-K atomics on zeroed scratch)
+    out2 = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=d)
+    ops().cutlass_scaled_mm(out2, a, b_nk.t(), a_s, b_s, None)
+    if kind == "int8" or m > 64:
+        assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "not reproducible"
+    else:   # fp8 decode split-K: fp32 atomics, order-dependent in the last bit
+        assert_gemm_close(out2.cpu(), out.cpu(), "fp8 split-K repeat", max_frac=0.12)

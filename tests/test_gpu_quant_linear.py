@@ -71,22 +71,31 @@ def test_apply_gptq(desc_act):
 
 
 def test_prefill_image_hook(monkeypatch):
-    """MI355X_PREPACK_WEIGHTS=1: process_weights_after_loading registers the weights' operand image; a
-    prefill-sized apply_awq then runs on it and returns the bits of the per-call path."""
+    """MI355X_PREPACK_WEIGHTS=1: process_weights_after_loading attaches the weights' operand image to the LAYER
+    (never a table keyed by a device address); a prefill-sized apply then runs on it and returns the bits of
+    the per-call path; the image goes away with the layer."""
     monkeypatch.setenv("MI355X_PREPACK_WEIGHTS", "1")
     dtype = torch.bfloat16
     k, n, g = 256, 512, 128
     qw, qz, sc, _, _ = make_awq(k, n, g, dtype, seed=8)
     d = dev()
-    qd, qzd, scd = lin().awq_process_weights(qw.to(d), g), qz.to(d), sc.to(d)
+
+    class FakeLayer:
+        pass
+    layer = FakeLayer()
+    layer.qweight, layer.qzeros, layer.scales = lin().awq_process_weights(qw.to(d), g), qz.to(d), sc.to(d)
     x = (torch.randn(1100, k, generator=torch.Generator().manual_seed(5)) * 0.5).to(dtype).to(d)
-    plain = lin().apply_awq(x, qd, scd, qzd, None, 8, g)
-    lin().register_prefill_image(qd, qzd, scd, False)
-    assert qd.data_ptr() in lin()._PREPACKED
-    try:
-        fast = lin().apply_awq(x, qd, scd, qzd, None, 8, g)
-        assert_bit_exact(fast, plain, "prefill image == per-call path")
-        small = lin().apply_awq(x[:64], qd, scd, qzd, None, 8, g)         # decode still streams int4
-        assert_bit_exact(small, lin().apply_awq(x[:64].clone(), qd, scd, qzd, None, 8, g), "decode unchanged")
-    finally:
-        lin()._PREPACKED.clear()
+    plain = lin().apply_awq(x, layer.qweight, layer.scales, layer.qzeros, None, 8, g)
+    assert lin().layer_image(layer, x) is None
+    lin().attach_prefill_image(layer, False)
+    img = lin().layer_image(layer, x)
+    assert img is not None and img[1:] == (n, k)
+    assert lin().layer_image(layer, x[:64]) is None            # decode keeps streaming the int4 words
+    fast = lin().apply_awq(x, layer.qweight, layer.scales, layer.qzeros, None, 8, g, image=img)
+    assert_bit_exact(fast, plain, "prefill image == per-call path")
+    fast2 = lin().apply_w4a16_image(x.view(2, 550, k), img[0], img[1], img[2], None)
+    assert_bit_exact(fast2.reshape(-1, n), plain, "apply_w4a16_image == per-call path")
+    small = lin().apply_awq(x[:64], layer.qweight, layer.scales, layer.qzeros, None, 8, g, image=img)
+    assert_bit_exact(small, lin().apply_awq(x[:64].clone(), layer.qweight, layer.scales, layer.qzeros, None, 8, g),
+                     "decode unchanged")
+    assert not hasattr(lin(), "_PREPACKED")

@@ -16,6 +16,7 @@ LIB_PATH = PKG_DIR / "libmi355x_hotpath.so"
 
 F16, BF16, F32 = 0, 1, 2
 KV_AUTO, KV_FP8_E4M3 = 0, 1          # mi355x_kv_cache_dtype
+ABI_VERSION = 3                      # the MI355X_ABI_VERSION the PROTOTYPES below were written for
 
 _P = c_void_p
 _I = c_int
@@ -112,6 +113,14 @@ def load() -> ctypes.CDLL:
             f"{path} is missing: build it with `python -m vllm_metax_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
     lib = ctypes.CDLL(str(path))
+    # a library of another ABI version may still export every symbol, with parameters inserted in the middle of
+    # the lists (version 2 did that): calling it would shift arguments into wild device pointers
+    lib.mi355x_abi_version.restype = _I
+    lib.mi355x_abi_version.argtypes = []
+    got = lib.mi355x_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{path} has C-ABI version {got}, these bindings are written for version {ABI_VERSION} "
+                          "(include/mi355x_hotpath.h): rebuild with `python -m vllm_metax_amd.build`")
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

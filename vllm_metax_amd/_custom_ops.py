@@ -1120,9 +1120,9 @@ def cutlass_scaled_mm(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
         raise RuntimeError("cutlass_scaled_mm: scales must be contiguous")
     if bias is not None and (bias.numel() != n or not bias.is_contiguous() or bias.dtype != out.dtype):
         raise RuntimeError("cutlass_scaled_mm: bad bias")
-    # small-M (decode) shapes split K across workgroups through an fp32 workspace
+    # small-M (decode) shapes split K across up to 8 workgroups, one fp32 / int32 partial slab [m, n] each
     if m <= 64:
-        ws = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        ws = torch.empty((8, m, n), dtype=torch.float32, device=a.device)
     elif m >= 1024 and k % 64 == 0:
         # prefill: scratch for the re-tiled operands, (roundup(m,16) + roundup(n,16)) * k bytes
         need = ((m + 15) // 16 * 16 + (n + 15) // 16 * 16) * k

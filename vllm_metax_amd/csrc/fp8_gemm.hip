@@ -17,11 +17,14 @@
 //             global to VGPRs, A staged through LDS in fragment-major order (lane-linear
 //             ds_read_b128), issue-early / write-late double buffering, XCD-aware tiles.
 //   small M : 64 x 64 tile, the 4 waves split K and are summed through LDS; optional
-//             split-K across workgroups through an fp32 workspace.
+//             split-K across workgroups through fp32 partial slabs [sk][m][n] summed in slab order by a finish
+//             kernel.  (Rounds 1-2 zeroed ONE [m, n] workspace with hipMemsetAsync and added into it with atomics:
+//             inside a captured HIP graph that sequence returned garbage from the second replay on — the cause of
+//             the non-finite logits of the `--quant fp8` job, scripts/debug_fp8_graph.py)
 //
 // int8 (W8A8): the SAME kernels instantiated with v_mfma_i32_16x16x32_i8 —
 // identical operand shape (8 consecutive-k bytes per lane), exact int32 accumulation (split-K
-// through int32 atomics), epilogue out = T(a_s * (b_s * float(acc)) + bias) in fp32 — the
+// through int32 partial slabs), epilogue out = T(a_s * (b_s * float(acc)) + bias) in fp32 — the
 // reference's int8 cutlass_scaled_mm (csrc/quantization/cutlass_w8a8/scaled_mm_entry.cu:34-39,
 // :84-140; epilogue order as tests/kernels/utils.py baseline_scaled_mm).
 #include "w4a16.cuh"   // pack_a_kernel / frag_swz: the packed operand image of the prefill path
@@ -329,7 +332,9 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
           const float as = a_scales[a_per_row ? row : 0];
           out[(int64_t)row * ldc + col] = out_cast<T>(Op::finish(acc[i][t][j], as, bs, bi));
         } else {
-          atomicAdd(ws + (int64_t)row * n + col, acc[i][t][j]);
+          // split K across workgroups: partial slab [blockIdx.y][m][n], summed in slab order by the finish
+          // kernel (no memset node, no atomics: deterministic, and safe to replay from a HIP graph)
+          ws[((int64_t)blockIdx.y * m + row) * n + col] = acc[i][t][j];
         }
       }
     }
@@ -557,16 +562,18 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
   }
 }
 
-// split-K epilogue: out = T(ws * a_s * b_s + bias)
+// split-K epilogue: out = T((slab 0 + slab 1 + ...) * a_s * b_s + bias), slabs added in index order
 template <typename T, typename Op>
 __global__ void fp8_gemm_finish_kernel(T* __restrict__ out, const typename Op::elem_t* __restrict__ ws,
                                        const float* __restrict__ a_scales, int a_per_row,
                                        const float* __restrict__ b_scales, int b_per_col,
-                                       const T* __restrict__ bias, int m, int n, int64_t ldc) {
+                                       const T* __restrict__ bias, int m, int n, int64_t ldc, int sk) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   const int row = blockIdx.y;
   if (col >= n) return;
-  const float v = Op::finish(ws[(int64_t)row * n + col], a_scales[a_per_row ? row : 0],
+  typename Op::elem_t acc = ws[(int64_t)row * n + col];
+  for (int s = 1; s < sk; ++s) acc += ws[((int64_t)s * m + row) * n + col];
+  const float v = Op::finish(acc, a_scales[a_per_row ? row : 0],
                              b_scales[b_per_col ? col : 0], bias ? to_f32(bias[col]) : 0.f);
   out[(int64_t)row * ldc + col] = out_cast<T>(v);
 }
@@ -647,18 +654,14 @@ static int run_fp8(const Fp8Args& g) {
   const int col_tiles = (g.n + 63) / 64;
   const int total_tiles = g.k / kF8BK;
   int sk = 1;
-  if (g.ws != nullptr && g.ws_elems >= (int64_t)g.m * g.n) {
-    while (col_tiles * sk < 256 && total_tiles / (sk * 2) >= 16) sk *= 2;
+  if (g.ws != nullptr) {
+    // one fp32 / int32 partial slab [m, n] per K split; only as many splits as the workspace holds
+    while (col_tiles * sk < 256 && total_tiles / (sk * 2) >= 16 &&
+           g.ws_elems >= (int64_t)(sk * 2) * g.m * g.n)
+      sk *= 2;
   }
   const int per_split = (total_tiles + sk - 1) / sk;
   sk = (total_tiles + per_split - 1) / per_split;
-  if (sk > 1) {
-    hipError_t e = hipMemsetAsync(g.ws, 0, (size_t)g.m * g.n * sizeof(float), g.stream);
-    if (e != hipSuccess) {
-      set_error("scaled_mm_fp8: hipMemsetAsync: %s", hipGetErrorString(e));
-      return MI355X_ELAUNCH;
-    }
-  }
   const int mt = (g.m + 15) / 16;
   dim3 grid(col_tiles, sk), block(256);
 #define LAUNCH_F8S(MTV)                                                                       \
@@ -674,8 +677,8 @@ static int run_fp8(const Fp8Args& g) {
   int rc = check_launch("scaled_mm_fp8(small)");
   if (rc || sk == 1) return rc;
   hipLaunchKernelGGL((fp8_gemm_finish_kernel<T, Op>), dim3((g.n + 255) / 256, g.m), dim3(256), 0,
-                     g.stream, out, reinterpret_cast<const typename Op::elem_t*>(g.ws), g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m,
-                     g.n, g.ldc);
+                     g.stream, out, reinterpret_cast<const typename Op::elem_t*>(g.ws), g.a_scales, a_per_row,
+                     g.b_scales, b_per_col, bias, g.m, g.n, g.ldc, sk);
   return check_launch("scaled_mm_fp8(finish)");
 }
 

@@ -426,8 +426,8 @@ void cutlass_scaled_mm(Tensor& out, const Tensor& a, const Tensor& b, const Tens
                 bias->scalar_type() == out.scalar_type());
   }
   Guard g(a);
-  Tensor ws;  // small-M (decode) shapes split K across workgroups through an fp32 workspace
-  if (m <= 64 && m > 0) ws = at::empty({m, n}, a.options().dtype(at::kFloat));
+  Tensor ws;  // small-M (decode) shapes split K across up to 8 workgroups, one 4-byte partial slab [m, n] each
+  if (m <= 64 && m > 0) ws = at::empty({8, m, n}, a.options().dtype(at::kFloat));
   else if (m >= 1024 && k % 64 == 0)   // prefill: scratch for the re-tiled operands (bytes / 4)
     ws = at::empty({(((m + 15) / 16 * 16 + (n + 15) / 16 * 16) * k + 3) / 4}, a.options().dtype(at::kFloat));
   auto fn = is_i8 ? mi355x_scaled_mm_int8 : mi355x_scaled_mm_fp8;   // scaled_mm_entry.cu:34-39 / new

@@ -58,6 +58,12 @@ class ModelConfig:
                            ffn=29696, vocab=152064, rope_theta=1e6, eps=1e-6, quant=quant, tp=tp)
 
     @staticmethod
+    def llama_geometry(quant="awq", layers=2, vocab=8192):
+        """A few layers at Llama-3-8B WIDTH (hidden 4096, 32 / 8 heads x 128, FFN 14336): what the fused decode /
+        image paths and the split-K GEMMs need to be selected — for end-to-end tests, not for the bench."""
+        return ModelConfig(name=f"llama-geometry-{layers}l", layers=layers, vocab=vocab, quant=quant)
+
+    @staticmethod
     def tiny(quant="awq"):
         return ModelConfig(name="tiny", hidden=512, layers=2, heads=8, kv_heads=2, head_dim=64,
                            ffn=1024, vocab=1024, quant=quant)
@@ -460,7 +466,8 @@ class HotPathModel:
         for i in range(self.cfg.layers):
             x, residual, _ = self._layer(i, x, residual, pos, slots, attn_fn)
         last = (cu[1:] - 1).long()
-        return self._logits_argmax(x[last].contiguous(), residual[last].contiguous())
+        self.last_prefill_logits = self._logits(x[last].contiguous(), residual[last].contiguous())
+        return self.last_prefill_logits.argmax(dim=-1)
 
     # ----------------------------------------------------------------- decode
     def setup_decode(self, num_seqs: int, start_len: int, max_seq_len: int):
@@ -514,6 +521,7 @@ class HotPathModel:
                                                pending, defer=True,
                                                attn_fused_fn=attn_fused_fn if self.fuse_attn_qkv else None)
         logits = self._logits(x, residual, pending)
+        self.last_logits = logits      # (inside a captured graph: a tensor of the graph's pool, rewritten by every replay)
         if self.fuse_greedy:
             # argmax + positions / seq_lens += 1 + the next step's slots: one launch instead of ~13 torch ones
             ops.greedy_advance(logits.contiguous(), self.d_tokens, self.d_positions, self.d_seq_lens, self.d_slots,
@@ -582,3 +590,130 @@ class HotPathModel:
         kv = num_seqs * mean_len * L.kv_heads * self.cfg.head_dim * 2 * kv_elt * self.cfg.layers
         head = self.lm_head.numel() * 2
         return {"weights": w, "kv": kv, "lm_head": head, "total": w + kv + head}
+
+
+class PluginSurfaceModel(HotPathModel):
+    """The SAME model driven only through what upstream vLLM reaches when this plugin is dropped in unchanged
+    (north_star): `quant_config.linear.apply_awq / apply_gptq` (= torch.ops.vllm._apply_awq / _apply_gptq),
+    `attention.backend.build_metadata + paged_attention_forward` (= Mi355xPagedAttentionImpl.forward), and
+    `torch.ops._C.{rms_norm, fused_add_rms_norm, rotary_embedding, silu_and_mul}` (vLLM's RMSNorm / RotaryEmbedding
+    / SiluAndMul.forward_cuda, ops/__init__.py) in the order of upstream's LlamaDecoderLayer.forward.
+    None of the cross-op fusions of HotPathModel (operand images, SILU epilogues, slab-consuming norms, the qkv
+    prologue of the decode attention, greedy_advance) is reachable from here — this is the measured cost of the
+    plain op surface; `patch/fused_layers.py` (register_patch) is what brings the fusions back under vLLM.
+    Sampling is torch.argmax + torch index arithmetic, as upstream's sampler / model runner do it."""
+
+    def __init__(self, *a, prepack_weights: bool = False, **kw):
+        super().__init__(*a, **kw)
+        import vllm_metax_amd._C  # noqa: F401  (registers torch.ops._C*)
+        from .attention import backend as B
+        from .quant_config import linear
+        self.B, self.linear = B, linear
+        cfg, d = self.cfg, self.cfg.head_dim
+        kvh = self.layers[0].kv_heads
+        nb = self.k_cache[0].shape[0]
+        # the backend's KV cache shape (2, nb, bs * kvh * d); k_cache / v_cache become views of it
+        self.kv_cache = [torch.zeros(B.kv_cache_shape(nb, self.BLOCK, kvh, d), dtype=self.k_cache[0].dtype,
+                                     device=self.device) for _ in range(cfg.layers)]
+        for i in range(cfg.layers):
+            self.k_cache[i], self.v_cache[i] = B.split_kv_cache(self.kv_cache[i], kvh, d)
+        self.workspace = B.DecodeWorkspace(self.max_seqs, self.layers[0].q_heads, d, self.max_len, self.dtype,
+                                           self.device)
+        # MI355X_PREPACK_WEIGHTS semantics of the plugin (off by default): the image belongs to the layer
+        self.images = {}
+        if prepack_weights and cfg.quant in ("awq", "gptq"):
+            for i, L in enumerate(self.layers):
+                for name in ("qkv", "o", "gate_up", "down"):
+                    q = getattr(L, name)
+                    self.images[(i, name)] = (ops.w4a16_prepack(q.qweight, q.qzeros, q.scales, cfg.quant == "gptq"),
+                                              q.n, q.k)
+
+    def _apply(self, i: int, name: str, x: torch.Tensor) -> torch.Tensor:
+        q: QLinear = getattr(self.layers[i], name)
+        if q.quant == "awq":
+            # the reference's declared qweight shape is [N, K/8] over [K/8, N] memory (awq.py:138)
+            return self.linear.apply_awq(x, q.qweight.view(q.n, -1), q.scales, q.qzeros, None, 8, q.group,
+                                         image=self.images.get((i, name)))
+        if q.quant == "gptq":
+            return self.linear.apply_gptq(x, q.qweight, q.scales, q.qzeros, None, q.g_idx, True, 4, q.group, False,
+                                          image=self.images.get((i, name)))
+        return q(x)        # fp8 / int8: dynamic activation quant + cutlass_scaled_mm, already plain ops
+
+    def _surface_layer(self, i, x, residual, positions, md):
+        L, cfg, C = self.layers[i], self.cfg, torch.ops._C
+        if residual is None:
+            residual = x
+            h = torch.empty_like(x)
+            C.rms_norm(h, x, L.ln1, cfg.eps)
+        else:
+            C.fused_add_rms_norm(x, residual, L.ln1, cfg.eps)
+            h = x
+        qkv = self._apply(i, "qkv", h)
+        q, k, v = qkv.split([L.q_size, L.kv_size, L.kv_size], dim=-1)
+        C.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin, True)
+        T = q.shape[0]
+        out = torch.empty(T, L.q_heads, cfg.head_dim, dtype=q.dtype, device=q.device)
+        self.B.paged_attention_forward(q.view(T, L.q_heads, cfg.head_dim), k.view(T, L.kv_heads, cfg.head_dim),
+                                       v.view(T, L.kv_heads, cfg.head_dim), self.kv_cache[i], md, out, L.kv_heads,
+                                       self.scale, None, self.kv_dtype, self.k_scale, self.v_scale)
+        o = self._all_reduce(self._apply(i, "o", out.view(T, L.q_size)))
+        C.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
+        gu = self._apply(i, "gate_up", o)
+        act = torch.empty(T, L.ffn, dtype=gu.dtype, device=gu.device)
+        C.silu_and_mul(act, gu)
+        return self._all_reduce(self._apply(i, "down", act)), residual
+
+    def _surface_logits(self, x, residual):
+        torch.ops._C.fused_add_rms_norm(x, residual, self.final_norm, self.cfg.eps)
+        return self._logits_from_hidden(x)
+
+    def _logits_from_hidden(self, x):
+        logits = torch.matmul(x, self.lm_head)
+        if self._collectives():
+            g = torch.empty(self.cfg.tp * logits.shape[0], logits.shape[1], dtype=logits.dtype, device=logits.device)
+            torch.distributed.all_gather_into_tensor(g, logits.contiguous(), group=self.tp_group)
+            logits = g.view(self.cfg.tp, logits.shape[0], logits.shape[1]).permute(1, 0, 2).reshape(logits.shape[0], -1)
+        return logits
+
+    def prefill(self, token_ids, seq_ids, context_len: int = 0):
+        n, q_len = token_ids.shape
+        dev = self.device
+        sid = torch.tensor(seq_ids, dtype=torch.int64, device=dev)
+        pos = (torch.arange(q_len, device=dev) + context_len).repeat(n)
+        slots = self._slots(sid.repeat_interleave(q_len), pos)
+        cu_cpu = [i * q_len for i in range(n + 1)]
+        cu = torch.tensor(cu_cpu, dtype=torch.int32, device=dev)
+        sl_cpu = [context_len + q_len] * n
+        seq_lens = torch.tensor(sl_cpu, dtype=torch.int32, device=dev)
+        L0 = self.layers[0]
+        md = self.B.build_metadata(cu, cu_cpu, seq_lens, sl_cpu, self.block_tables[sid], slots, n * q_len, q_len,
+                                   context_len + q_len, L0.q_heads, self.cfg.head_dim, self.dtype, self.workspace,
+                                   L0.kv_heads, self.BLOCK)
+        x, residual = self.embed[token_ids.reshape(-1)], None
+        for i in range(self.cfg.layers):
+            x, residual = self._surface_layer(i, x, residual, pos, md)
+        last = (cu[1:] - 1).long()
+        self.last_prefill_logits = self._surface_logits(x[last].contiguous(), residual[last].contiguous())
+        return self.last_prefill_logits.argmax(dim=-1)
+
+    def _decode_body(self):
+        n = self.d_tokens.shape[0]
+        L0 = self.layers[0]
+        cu_cpu = list(range(n + 1))
+        if getattr(self, "_d_cu", None) is None or self._d_cu.numel() != n + 1:
+            self._d_cu = torch.arange(n + 1, dtype=torch.int32, device=self.device)
+        # host copies as vLLM's CommonAttentionMetadata carries them; the launch geometry comes from the fixed
+        # maximum (HIP-graph capture), the kernels read the true lengths from d_seq_lens on the device
+        md = self.B.build_metadata(self._d_cu, cu_cpu, self.d_seq_lens, [self.d_max_seq_len] * n, self.d_bt,
+                                   self.d_slots, n, 1, self.d_max_seq_len, L0.q_heads, self.cfg.head_dim, self.dtype,
+                                   self.workspace, L0.kv_heads, self.BLOCK, fixed_decode_len=self.d_max_seq_len)
+        x, residual = self.embed[self.d_tokens], None
+        for i in range(self.cfg.layers):
+            x, residual = self._surface_layer(i, x, residual, self.d_positions, md)
+        logits = self._surface_logits(x, residual)
+        self.last_logits = logits
+        self.d_tokens.copy_(logits.argmax(dim=-1))
+        self.d_positions.add_(1)
+        self.d_seq_lens.add_(1)
+        last = self.d_bt.shape[1] * self.BLOCK - 1
+        self.d_slots.copy_(self._slots(self.d_seq_ids, self.d_positions.clamp(max=last)))

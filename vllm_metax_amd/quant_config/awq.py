@@ -35,10 +35,13 @@ class AWQLinearMethod(_AWQLinearMethod):
             linear.awq_process_weights(layer.qweight.data, self.quant_config.group_size),
             requires_grad=False)
         if self.quant_config.group_size % 32 == 0:
-            linear.register_prefill_image(layer.qweight.data, layer.qzeros.data, layer.scales.data, False)
+            linear.attach_prefill_image(layer, False)
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor,
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        img = linear.layer_image(layer, x)
+        if img is not None:
+            return torch.ops.vllm._apply_w4a16_image(x, img[0], img[1], img[2], bias)
         return torch.ops.vllm._apply_awq(x, layer.qweight, layer.scales, layer.qzeros, bias,
                                          self.quant_config.pack_factor,
                                          self.quant_config.group_size)
@@ -47,3 +50,9 @@ class AWQLinearMethod(_AWQLinearMethod):
 direct_register_custom_op(op_name="_apply_awq", op_func=linear.apply_awq, mutates_args=[],
                           fake_impl=linear.apply_awq_fake,
                           tags=(torch.Tag.needs_fixed_stride_order,))
+try:   # shared with gptq.py: whichever module is imported first registers it
+    direct_register_custom_op(op_name="_apply_w4a16_image", op_func=linear.apply_w4a16_image, mutates_args=[],
+                              fake_impl=linear.apply_w4a16_image_fake,
+                              tags=(torch.Tag.needs_fixed_stride_order,))
+except RuntimeError:
+    pass

@@ -33,10 +33,13 @@ class GPTQLinearMethod(_GPTQLinearMethod):
         layer.g_idx = torch.nn.Parameter(g_idx, requires_grad=False)
         layer.exllama_state = ExllamaState.READY
         if self.quant_config.weight_bits == 4 and not self.quant_config.desc_act:
-            linear.register_prefill_image(layer.qweight.data, layer.qzeros.data, layer.scales.data, True)
+            linear.attach_prefill_image(layer, True)
 
     def apply(self, layer: torch.nn.Module, x: torch.Tensor,
               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        img = linear.layer_image(layer, x)
+        if img is not None:
+            return torch.ops.vllm._apply_w4a16_image(x, img[0], img[1], img[2], bias)
         return torch.ops.vllm._apply_gptq(
             x, layer.qweight, layer.scales, layer.qzeros, bias, layer.g_idx,
             layer.exllama_state == ExllamaState.READY, self.quant_config.weight_bits,
@@ -46,3 +49,9 @@ class GPTQLinearMethod(_GPTQLinearMethod):
 direct_register_custom_op(op_name="_apply_gptq", op_func=linear.apply_gptq, mutates_args=[],
                           fake_impl=linear.apply_gptq_fake,
                           tags=(torch.Tag.needs_fixed_stride_order,))
+try:   # shared with awq.py
+    direct_register_custom_op(op_name="_apply_w4a16_image", op_func=linear.apply_w4a16_image, mutates_args=[],
+                              fake_impl=linear.apply_w4a16_image_fake,
+                              tags=(torch.Tag.needs_fixed_stride_order,))
+except RuntimeError:
+    pass

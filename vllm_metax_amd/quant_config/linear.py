@@ -14,24 +14,51 @@ from .. import envs
 
 # Optional (MI355X_PREPACK_WEIGHTS=1): the prefill GEMM's weight operand image, dequantised once in
 # process_weights_after_loading instead of inside every prefill-sized awq_gemm / gptq_gemm call
-# (n * k * 2 bytes per layer; bit-identical results).  Keyed by the repacked qweight's address so that the
-# reference's _apply_awq / _apply_gptq op signatures stay as they are.
-_PREPACKED: dict = {}
+# (n * k * 2 bytes per layer; bit-identical results).  The image belongs to the LAYER: the linear methods
+# keep it as `layer._mi355x_prefill_image` and hand it to apply_awq / apply_gptq (`image=`) or to
+# apply_w4a16_image — never a table keyed by a device address (a freed-and-reused address would serve
+# another layer's weights).
+PREFILL_IMAGE_MIN_M = 1024
+IMAGE_ATTR = "_mi355x_prefill_image"
 
 
-def register_prefill_image(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
-                           gptq_zeros: bool) -> None:
+def make_prefill_image(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                       gptq_zeros: bool):
+    """(image, n, k) for a repacked 4-bit layer, or None when the switch is off / the shape has no image."""
     if not envs.MI355X_PREPACK_WEIGHTS or scales.dtype == torch.float32:
-        return
+        return None
     n = scales.shape[1]
     k = qweight.numel() * 8 // n
     if n % 64 or k % 32 or (k // scales.shape[0]) % 32:
-        return
-    _PREPACKED[qweight.data_ptr()] = (ops.w4a16_prepack(qweight, qzeros, scales, gptq_zeros), n, k)
+        return None
+    return ops.w4a16_prepack(qweight, qzeros, scales, gptq_zeros), n, k
 
 
-def _prefill_image(qweight: torch.Tensor, m: int):
-    return _PREPACKED.get(qweight.data_ptr()) if m >= 1024 else None
+def attach_prefill_image(layer, gptq_zeros: bool) -> None:
+    """process_weights_after_loading hook: keep the image on the layer object (dropped with it)."""
+    setattr(layer, IMAGE_ATTR, make_prefill_image(layer.qweight.data, layer.qzeros.data, layer.scales.data,
+                                                  gptq_zeros))
+
+
+def layer_image(layer, x: torch.Tensor):
+    """The layer's image when this call is prefill-sized and contiguous, else None."""
+    img = getattr(layer, IMAGE_ATTR, None)
+    if img is None or x.numel() // x.shape[-1] < PREFILL_IMAGE_MIN_M or not x.is_contiguous():
+        return None
+    return img
+
+
+def apply_w4a16_image(x: torch.Tensor, image: torch.Tensor, n: int, k: int,
+                      bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """The prefill-sized linear on a load-time weight image (registered as torch.ops.vllm._apply_w4a16_image)."""
+    out = ops.w4a16_gemm_prepacked(x.reshape(-1, x.shape[-1]), image, n, k)
+    if bias is not None:
+        out.add_(bias)
+    return out.reshape(x.shape[:-1] + (n,))
+
+
+def apply_w4a16_image_fake(x, image, n, k, bias):
+    return torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
 
 
 def awq_process_weights(qweight: torch.Tensor, group_size: int) -> torch.Tensor:
@@ -43,8 +70,8 @@ def awq_process_weights(qweight: torch.Tensor, group_size: int) -> torch.Tensor:
 
 
 def apply_awq(x: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor,
-              bias: Optional[torch.Tensor], pack_factor: int, group_size: int) -> torch.Tensor:
-    """ref: awq.py:118-159."""
+              bias: Optional[torch.Tensor], pack_factor: int, group_size: int, image=None) -> torch.Tensor:
+    """ref: awq.py:118-159.  `image`: the layer's load-time prefill image (make_prefill_image), optional."""
     reshaped_x = x.reshape(-1, x.shape[-1])
     if group_size % 32:
         out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor,)
@@ -56,8 +83,8 @@ def apply_awq(x: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzer
         temp_space = torch.empty(0, dtype=torch.float32, device=x.device)
         if reshaped_x.shape[0] <= 64:             # split-K workspace only matters for decode
             temp_space = torch.zeros(reshaped_x.shape[0], n, dtype=torch.float32, device=x.device)
-        img = _prefill_image(qweight, reshaped_x.shape[0])
-        if img is not None and reshaped_x.stride(-1) == 1:
+        img = image if reshaped_x.shape[0] >= PREFILL_IMAGE_MIN_M else None
+        if img is not None and reshaped_x.is_contiguous():
             out = ops.w4a16_gemm_prepacked(reshaped_x, img[0], img[1], img[2])
         else:
             out = ops.awq_gemm(reshaped_x, qweight, qzeros, scales, pack_factor, temp_space,
@@ -87,8 +114,8 @@ def gptq_process_weights(qweight: torch.Tensor, g_idx: torch.Tensor, desc_act: b
 
 def apply_gptq(x: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor,
                bias: Optional[torch.Tensor], g_idx: torch.Tensor, use_exllama: bool,
-               weight_bits: int, group_size: int, desc_act: bool) -> torch.Tensor:
-    """ref: gptq.py:180-229."""
+               weight_bits: int, group_size: int, desc_act: bool, image=None) -> torch.Tensor:
+    """ref: gptq.py:180-229.  `image`: the layer's load-time prefill image, optional."""
     reshaped_x = x.reshape(-1, x.shape[-1])
     out_shape = x.shape[:-1] + (qweight.shape[-1],)
     perm_space = torch.empty(0)
@@ -99,7 +126,7 @@ def apply_gptq(x: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qze
     if reshaped_x.shape[0] <= 64:
         temp_space = torch.zeros(reshaped_x.shape[0], qweight.shape[1], dtype=torch.float32,
                                  device=x.device)
-    img = _prefill_image(qweight, reshaped_x.shape[0]) if (weight_bits == 4 and not desc_act) else None
+    img = image if (weight_bits == 4 and not desc_act and reshaped_x.shape[0] >= PREFILL_IMAGE_MIN_M) else None
     if img is not None and reshaped_x.is_contiguous():
         out = ops.w4a16_gemm_prepacked(reshaped_x, img[0], img[1], img[2])
     else:
