@@ -236,6 +236,11 @@ def instrument(model, timer: EventTimer):
     wrap("rms_norm_image", lambda x, w, eps: (0.0, float(x.numel() * x.element_size() * 2)), record_as="rms_norm")
     wrap("fused_add_rms_norm_image", lambda x, r, w, eps: (0.0, float(x.numel() * x.element_size() * 5)),
          record_as="fused_add_rms_norm")
+    wrap("rms_norm_dynamic_per_token_quant",
+         lambda out, inp, w, sc, eps, ub=None, res=None:
+         (0.0, float(inp.numel() * inp.element_size() * (3 if res is not None else 1) + out.numel())))
+    wrap("dynamic_per_token_scaled_fp8_quant",
+         lambda out, inp, sc, ub=None: (0.0, float(inp.numel() * inp.element_size() + out.numel())))
     wrap("greedy_advance", lambda logits, *a, **k: (0.0, float(logits.numel() * logits.element_size())))
     wrap("rotary_reshape_and_cache",
          lambda pos, key, value, kc, *a, **k: (0.0, 2.0 * key.numel() * (2 + kc.element_size())),

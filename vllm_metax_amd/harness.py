@@ -69,6 +69,15 @@ class ModelConfig:
                            ffn=1024, vocab=1024, quant=quant)
 
 
+class QuantAct:
+    """An activation matrix already quantised per token (fp8 bytes + one float32 scale per row): what the fused
+    norm + quant op hands to the W8A8 linear (rms_norm_dynamic_per_token_quant)."""
+
+    def __init__(self, data: torch.Tensor, scales: torch.Tensor, dtype):
+        self.data, self.scales, self.dtype = data, scales, dtype
+        self.shape, self.device = data.shape, data.device
+
+
 class QLinear:
     """One (column- or row-parallel shard of a) linear layer with synthetic weights.
 
@@ -175,10 +184,14 @@ class QLinear:
             return ops.gptq_gemm(x, self.qweight, self.qzeros, self.scales, self.g_idx, True, 4,
                                  self.group, torch.empty(0), ws, x.dtype == torch.bfloat16)
         if self.quant == "fp8":
-            xq = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
-            xs = torch.empty(m, 1, dtype=torch.float32, device=x.device)
-            ops.dynamic_per_token_scaled_fp8_quant(xq, x, xs, None)
-            out = torch.empty(m, self.n, dtype=x.dtype, device=x.device)
+            if isinstance(x, QuantAct):      # quantised by the producer (fused norm + quant)
+                xq, xs, odt = x.data, x.scales, x.dtype
+            else:
+                xq = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+                xs = torch.empty(m, 1, dtype=torch.float32, device=x.device)
+                ops.dynamic_per_token_scaled_fp8_quant(xq, x, xs, None)
+                odt = x.dtype
+            out = torch.empty(m, self.n, dtype=odt, device=xq.device)
             ops.cutlass_scaled_mm(out, xq, self.weight, xs, self.w_scale, None)
             return out
         if self.quant == "int8":
@@ -312,6 +325,10 @@ class HotPathModel:
         # prefill: the norms in front of the qkv / gate_up GEMMs write the GEMM's activation operand image
         # (mi355x_*rms_norm_image) instead of a row-major tensor the GEMM re-tiles; "0": row-major
         self.norm_image = os.environ.get("MI355X_NORM_IMAGE", "1") != "0"
+        # fp8 weights: the norms in front of qkv / gate_up quantise their output per token themselves
+        # (rms_norm_dynamic_per_token_quant, the reference's fused op csrc/quantization/fused_kernels/): one launch
+        # and one pass over the activations less per GEMM; "0": rms_norm, then dynamic_per_token_scaled_fp8_quant
+        self.fuse_norm_quant = os.environ.get("MI355X_FUSE_NORM_QUANT", "1") != "0"
 
     # ---------------------------------------------------------------- helpers
     def _collectives(self) -> bool:
@@ -323,6 +340,14 @@ class HotPathModel:
         if self._collectives():
             torch.distributed.all_reduce(x, group=self.tp_group)
         return x
+
+    def _norm_quant(self, x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor) -> QuantAct:
+        """rms_norm (fused add when `residual` is given: it then receives x + residual) + dynamic per-token fp8
+        quantisation in one launch."""
+        q = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+        sc = torch.empty(x.shape[0], 1, dtype=torch.float32, device=x.device)
+        ops.rms_norm_dynamic_per_token_quant(q, x.contiguous(), weight, sc, self.cfg.eps, None, residual)
+        return QuantAct(q, sc, x.dtype)
 
     def _slots(self, seq_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
         blk = self.block_tables[seq_ids.long(), (positions // self.BLOCK).long()].long()
@@ -338,14 +363,19 @@ class HotPathModel:
         fuse = defer and self.cfg.tp == 1   # with tp > 1 the all-reduce sits between GEMM and norm
         use_img = (not defer) and self.norm_image and x.shape[0] >= 1024 and pending[1] == 0 \
             and L.qkv.image() is not None and L.gate_up.image() is not None
+        nq = cfg.quant == "fp8" and self.fuse_norm_quant and x.dtype != torch.float32 and pending[1] == 0
         if residual is None:
             residual = x.clone()
             h = ops.rms_norm_image(x, L.ln1, cfg.eps) if use_img else None
+            if h is None and nq:
+                h = self._norm_quant(x, None, L.ln1)
             if h is None:
                 h = torch.empty_like(x)
                 ops.rms_norm(h, x, L.ln1, cfg.eps)
         else:
             h = ops.fused_add_rms_norm_image(x, residual, L.ln1, cfg.eps) if use_img else None
+            if h is None and nq:
+                h = self._norm_quant(x, residual, L.ln1)
             if h is None:
                 ops.fused_add_rms_norm_slabs(x, residual, L.ln1, pending[0], pending[1], cfg.eps)
                 h = x
@@ -387,16 +417,18 @@ class HotPathModel:
                                       self.v_scale)
         if attn is None:
             attn = attn_fn(i, q.view(-1, L.q_heads, cfg.head_dim))
-        if fuse:
+        if fuse and not nq:
             o, slabs, sk = L.o.deferred(attn.view(-1, L.q_size))
             ops.fused_add_rms_norm_slabs(o, residual, L.ln2, slabs, sk, cfg.eps)
         else:
             o = self._all_reduce(L.o(attn if isinstance(attn, ops.PackedOperand) else attn.view(-1, L.q_size)))
             o_img = ops.fused_add_rms_norm_image(o, residual, L.ln2, cfg.eps) if use_img else None
-            if o_img is None:
-                ops.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
-            else:
+            if o_img is not None:
                 o = o_img
+            elif nq:
+                o = self._norm_quant(o, residual, L.ln2)
+            else:
+                ops.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
         act = L.gate_up.silu_mul(o)            # prefill-sized AWQ: fused into the GEMM epilogue
         if act is None:
             gu = L.gate_up(o)
@@ -415,11 +447,12 @@ class HotPathModel:
         ops.fused_add_rms_norm_slabs(x, residual, self.final_norm, pending[0], pending[1], self.cfg.eps)
         logits = torch.matmul(x, self.lm_head)
         if self._collectives():
-            gathered = torch.empty(self.cfg.tp * logits.shape[0], logits.shape[1], dtype=logits.dtype,
-                                   device=logits.device)
+            # (a 1-rank rehearsal group of a tp > 1 shard gathers only its own vocabulary slice)
+            ws = torch.distributed.get_world_size(self.tp_group)
+            gathered = torch.empty(ws * logits.shape[0], logits.shape[1], dtype=logits.dtype, device=logits.device)
             torch.distributed.all_gather_into_tensor(gathered, logits.contiguous(), group=self.tp_group)
-            # [tp * M, V/tp] -> [M, V]: rank r owns vocabulary slice r
-            logits = gathered.view(self.cfg.tp, logits.shape[0], logits.shape[1]).permute(1, 0, 2) \
+            # [ws * M, V/tp] -> [M, V]: rank r owns vocabulary slice r
+            logits = gathered.view(ws, logits.shape[0], logits.shape[1]).permute(1, 0, 2) \
                              .reshape(logits.shape[0], -1)
         return logits
 
@@ -670,9 +703,10 @@ class PluginSurfaceModel(HotPathModel):
     def _logits_from_hidden(self, x):
         logits = torch.matmul(x, self.lm_head)
         if self._collectives():
-            g = torch.empty(self.cfg.tp * logits.shape[0], logits.shape[1], dtype=logits.dtype, device=logits.device)
+            ws = torch.distributed.get_world_size(self.tp_group)
+            g = torch.empty(ws * logits.shape[0], logits.shape[1], dtype=logits.dtype, device=logits.device)
             torch.distributed.all_gather_into_tensor(g, logits.contiguous(), group=self.tp_group)
-            logits = g.view(self.cfg.tp, logits.shape[0], logits.shape[1]).permute(1, 0, 2).reshape(logits.shape[0], -1)
+            logits = g.view(ws, logits.shape[0], logits.shape[1]).permute(1, 0, 2).reshape(logits.shape[0], -1)
         return logits
 
     def prefill(self, token_ids, seq_ids, context_len: int = 0):
