@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 3   /* 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
+#define MI355X_ABI_VERSION 4   /* 4: + paged_prefill_attention_alibi (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
                                 * 2 was BREAKING (kv_cache_dtype / k_scale / v_scale inserted before `stream` in reshape_and_cache*,
                                 * paged_attention_v1/_v2, paged_prefill_attention): a binding must refuse a library whose
                                 * mi355x_abi_version() differs from the version it was written for (vllm_metax_amd/_abi.py does) */
@@ -165,7 +165,8 @@ int mi355x_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
  * reshape_and_cache).  q/out [total_q, num_heads, head_size] packed by
  * cu_seqlens_q int32 [num_seqs+1]; seq_lens int32 [num_seqs] = context + new.
  * sliding_window W > 0: a query sees only its last W keys (the call site's window_size = (W-1, 0));
- * softcap c > 0: scores become c * tanh(s / c) before the mask; 0 = off (both run a general kernel).
+ * softcap c > 0: scores become c * tanh(s / c) before the mask; 0 = off.  For head_size 128 / block_size 16 /
+ * 16-bit types both run on the MFMA kernel (a separate instantiation), other shapes on the general kernel.
  * ref (call site, third-party kernel): vllm_metax/v1/attention/backends/
  *      flash_attn.py:725-747; semantic oracle tests/kernels/attention/
  *      test_flash_attn.py:27-80. */
@@ -180,6 +181,20 @@ int mi355x_paged_prefill_attention(void* out, const void* query, const void* key
                                    int dtype, int kv_cache_dtype, const float* k_scale,
                                    const float* v_scale, int sliding_window, float softcap,
                                    mi355x_stream stream);
+/* The same with the call site's alibi_slopes (float [num_heads] or NULL): slope[head] * (key position - query
+ * position) is added to the scaled (and capped) score — the bias of the decode kernel
+ * (csrc/attention/attention_kernels.cuh:286) at every query position.  MFMA kernel shapes only (ABI 4). */
+int mi355x_paged_prefill_attention_alibi(void* out, const void* query, const void* key_cache,
+                                         const void* value_cache, int num_seqs, int num_heads,
+                                         int num_kv_heads, int head_size, int block_size,
+                                         float scale, const int* block_tables,
+                                         const int* seq_lens, const int* cu_seqlens_q,
+                                         int max_query_len, int max_num_blocks_per_seq,
+                                         int64_t q_stride, int64_t out_stride,
+                                         int64_t kv_block_stride, int64_t kv_head_stride,
+                                         int dtype, int kv_cache_dtype, const float* k_scale,
+                                         const float* v_scale, int sliding_window, float softcap,
+                                         const float* alibi_slopes, mi355x_stream stream);
 
 /* ------------------------------------------------------------- layernorm --
  * ref: csrc/layernorm_kernels.cu:141-162 (rms_norm), :174-217 (fused_add). */

@@ -203,7 +203,8 @@ def paged_attention_v2(query, key_cache, value_cache, num_kv_heads, scale, block
 
 
 def paged_prefill_attention(query, key_cache, value_cache, num_kv_heads, scale, block_tables,
-                            seq_lens, cu_seqlens_q, sliding_window=None, softcap=None) -> torch.Tensor:
+                            seq_lens, cu_seqlens_q, sliding_window=None, softcap=None,
+                            alibi_slopes=None) -> torch.Tensor:
     """Varlen causal (bottom-right aligned) GQA attention of the new tokens against the
     paged cache.  The arithmetic at the reference call site
     (vllm_metax/v1/attention/backends/flash_attn.py:725-747) is inside the closed
@@ -227,6 +228,11 @@ def paged_prefill_attention(query, key_cache, value_cache, num_kv_heads, scale, 
             ki = torch.arange(L)[None, :]
             if softcap:                                     # test_flash_attn.py:66-67: before the mask
                 sc = softcap * torch.tanh(sc / softcap)
+            if alibi_slopes is not None:
+                # slope * (key position - query position): the decode kernel's bias (attention_kernels.cuh:286,
+                # slope * (tok - seq_len + 1) for the one query at seq_len - 1) at every query position; the
+                # reference's prefill oracle has no ALiBi case: parity unpinned
+                sc = sc + float(alibi_slopes[h]) * (ki - (qi + ctx)).float()
             sc = sc.masked_fill(ki > (qi + ctx), float("-inf"))
             if sliding_window:                              # :60-65: keys pos - W + 1 .. pos stay visible
                 sc = sc.masked_fill(ki < (qi + ctx - sliding_window + 1), float("-inf"))

@@ -22,7 +22,8 @@ def ops():
     return _custom_ops
 
 
-def _run(q_lens, seq_lens, H, KVH, D, bs, dtype, seed=0, poison_tail=False):
+def _run(q_lens, seq_lens, H, KVH, D, bs, dtype, seed=0, poison_tail=False, window=None, softcap=None, alibi=False,
+         kv_scale=1.0):
     torch.manual_seed(seed)
     S = len(q_lens)
     max_blocks = (max(seq_lens) + bs - 1) // bs
@@ -37,9 +38,12 @@ def _run(q_lens, seq_lens, H, KVH, D, bs, dtype, seed=0, poison_tail=False):
     cu[1:] = torch.tensor(q_lens).cumsum(0)
     T = int(cu[-1])
     scale = D ** -0.5
-    q = (torch.randn(T, H, D) * 0.5).to(dtype)
+    q = (torch.randn(T, H, D) * 0.5 * kv_scale).to(dtype)
     sl = torch.tensor(seq_lens, dtype=torch.int32)
-    ref = R.paged_prefill_attention(q, kc, vc, KVH, scale, bt, sl, cu)
+    slopes = None
+    if alibi:      # geometric slopes, as ALiBi models use them
+        slopes = torch.tensor([2.0 ** (-8.0 * (h + 1) / H) for h in range(H)], dtype=torch.float32)
+    ref = R.paged_prefill_attention(q, kc, vc, KVH, scale, bt, sl, cu, window, softcap, slopes)
     if poison_tail:
         for s, L in enumerate(seq_lens):
             if L % bs:
@@ -49,7 +53,8 @@ def _run(q_lens, seq_lens, H, KVH, D, bs, dtype, seed=0, poison_tail=False):
     d = dev()
     out = torch.full((T, H, D), float("nan"), dtype=dtype, device=d)
     ops().paged_prefill_attention(out, q.to(d), kc.to(d), vc.to(d), KVH, scale, bt.to(d), sl.to(d),
-                                  cu.to(d), max(q_lens), bs)
+                                  cu.to(d), max(q_lens), bs, "auto", None, None, window, softcap,
+                                  slopes.to(d) if slopes is not None else None)
     torch.cuda.synchronize()
     eps = {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7, torch.float32: 2.0 ** -23}[dtype]
     assert_close_rel(out, ref, 2e-3, "prefill", abs_floor=eps * ref.float().abs().max().item())
@@ -65,6 +70,35 @@ def _run(q_lens, seq_lens, H, KVH, D, bs, dtype, seed=0, poison_tail=False):
 def test_prefill_llama_heads(dtype, spec):
     q_lens, seq_lens = spec
     _run(q_lens, seq_lens, 8, 2, 128, 16, dtype, poison_tail=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("window,softcap,alibi", [(256, None, False), (None, 50.0, False), (256, 50.0, False),
+                                                  (None, None, True), (100, 30.0, True), (1, None, False),
+                                                  (17, None, False), (4096, None, False)])
+@pytest.mark.parametrize("spec", [
+    ([130, 7, 64], [130, 300, 64]),                   # pure prefill + chunked (context > 0)
+    ([300], [813]),                                   # window edge inside the context
+    ([32, 1, 200], [1000, 77, 200]),                  # long context: whole key stages below the window are skipped
+    ([513], [513]),
+])
+def test_prefill_window_softcap_alibi_on_the_mfma_kernel(dtype, window, softcap, alibi, spec):
+    """The optional arguments of the reference call site (flash_attn.py:725-747: window_size, softcap,
+    alibi_slopes) on the MFMA kernel (head 128, block 16): sliding windows from 1 key to longer than the
+    sequence, soft-cap, ALiBi and their combinations, with context > 0 and poisoned cache tails.  Scores are made
+    large enough (q scaled up) for the cap to bite.  Window / cap semantics are pinned by the reference-generated
+    fixture ref_flash_paged_opts (tests/test_gpu_ref_fixtures.py); ALiBi on the prefill path is parity unpinned
+    (the reference's prefill oracle has no ALiBi case; the bias is the decode kernel's)."""
+    q_lens, seq_lens = spec
+    _run(q_lens, seq_lens, 8, 2, 128, 16, dtype, seed=4, poison_tail=True, window=window, softcap=softcap,
+         alibi=alibi, kv_scale=4.0 if softcap else 1.0)
+
+
+def test_prefill_opts_generic_shapes_still_served():
+    """head sizes / block sizes the MFMA kernel does not take keep the general kernel for window / soft-cap."""
+    _run([9, 33], [20, 33], 4, 2, 64, 16, torch.bfloat16, seed=3, window=8, softcap=20.0)
+    with pytest.raises(RuntimeError):
+        _run([9], [20], 4, 2, 64, 16, torch.bfloat16, seed=3, alibi=True)
 
 
 def test_prefill_gqa_32_8_chunk():

@@ -20,10 +20,16 @@ def register():
 
 
 def register_patch():
-    """ref: vllm_metax/__init__.py:92-93 — the reference monkey-patches vLLM for MACA symbol
-    names (mccl*, mc* runtime); on ROCm upstream already binds librccl / libamdhip64, so there
-    is nothing to patch."""
-    return None
+    """ref: vllm_metax/__init__.py:92-93 (`import vllm_metax.patch`).  The reference's patches rename MACA
+    symbols (mccl*, mc* runtime) — not needed on ROCm, upstream already binds librccl / libamdhip64.  This
+    plugin's patches route upstream's Llama / Qwen2 MLP and decoder-layer forwards through the fused MI355X
+    entry points (patch/fused_layers.py), falling through to the original forward for anything not covered.
+    MI355X_FUSED_LAYERS=0 leaves vLLM unpatched (plain op surface)."""
+    from . import envs
+    if not envs.MI355X_FUSED_LAYERS:
+        return []
+    from . import patch
+    return patch.apply()
 
 
 def register_ops():

@@ -275,12 +275,25 @@ def paged_prefill_attention(out: torch.Tensor, query: torch.Tensor, key_cache: t
                             block_size: int, kv_cache_dtype: str = "auto",
                             k_scale: Optional[torch.Tensor] = None,
                             v_scale: Optional[torch.Tensor] = None, sliding_window: Optional[int] = None,
-                            softcap: Optional[float] = None) -> None:
+                            softcap: Optional[float] = None, alibi_slopes: Optional[torch.Tensor] = None) -> None:
     """Varlen causal attention of the new tokens against the paged cache (the role of
-    flash_attn_varlen_func(block_table=...) at the reference call site
+    flash_attn_varlen_func(block_table=..., window_size, softcap, alibi_slopes) at the reference call site
     vllm_metax/v1/attention/backends/flash_attn.py:725-747)."""
-    _dev(out, query, key_cache, value_cache, block_tables, seq_lens, cu_seqlens_q)
+    _dev(out, query, key_cache, value_cache, block_tables, seq_lens, cu_seqlens_q, alibi_slopes)
     kvd, ks, vs = _kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale)
+    if alibi_slopes is not None:
+        if alibi_slopes.dtype != torch.float32 or alibi_slopes.numel() != query.size(1) \
+                or not alibi_slopes.is_contiguous():
+            raise RuntimeError("paged_prefill_attention: alibi_slopes must be a contiguous float32 [num_heads]")
+        rc = _abi.load().mi355x_paged_prefill_attention_alibi(
+            _ptr(out), _ptr(query), _ptr(key_cache), _ptr(value_cache), seq_lens.size(0),
+            query.size(1), num_kv_heads, query.size(2), block_size, float(scale),
+            _ptr(block_tables), _ptr(seq_lens), _ptr(cu_seqlens_q), max_query_len,
+            block_tables.size(1), query.stride(0), out.stride(0), key_cache.stride(0),
+            key_cache.stride(1), _dt(query), kvd, ks, vs, int(sliding_window or 0), float(softcap or 0.0),
+            _ptr(alibi_slopes), _stream())
+        _abi.check(rc, "paged_prefill_attention")
+        return
     rc = _abi.load().mi355x_paged_prefill_attention(
         _ptr(out), _ptr(query), _ptr(key_cache), _ptr(value_cache), seq_lens.size(0),
         query.size(1), num_kv_heads, query.size(2), block_size, float(scale),

@@ -252,12 +252,10 @@ def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
                          md.seq_lens[:nd], block_size, md.max_decode_seq_len, alibi_slopes,
                          kv_cache_dtype, k_scale, v_scale, md.use_v1)
     if md.num_prefills > 0:
-        if alibi_slopes is not None:
-            raise RuntimeError("ALiBi is only supported on the decode path of this backend")
         ops.paged_prefill_attention(output[ndt:n], query[ndt:n], key_cache, value_cache,
                                     num_kv_heads, scale, md.block_table[nd:], md.seq_lens[nd:],
                                     md.prefill_query_start_loc, md.max_prefill_query_len, block_size,
-                                    kv_cache_dtype, k_scale, v_scale, sliding_window, softcap)
+                                    kv_cache_dtype, k_scale, v_scale, sliding_window, softcap, alibi_slopes)
     return output
 
 

@@ -98,7 +98,13 @@ constexpr float kNegBig = -1.0e30f;
 // [row tile of 16 tokens][k tile of 32][64 slots of 8 elements], slot lr * 16 + (lc ^ g(lr)) = O[16 mt + lc][32 kt +
 // 8 lr ..] over the [tokens, num_heads * 128] matrix — the re-tiling launch in front of that GEMM disappears, and
 // the epilogue's stores become two 256-byte runs per instruction instead of sixteen 32-byte ones.
-template <typename T, bool KV8, bool IMG = false>
+// OPTS: the optional arguments of the call site (flash_attn.py:725-747) — window_size = (W - 1, 0), softcap,
+// alibi_slopes — on the same MFMA kernel: the window skips the key stages below the workgroup's first visible key
+// and masks per row, the cap costs one tanh per score (cap * tanh(s / cap), before the mask:
+// tests/kernels/attention/test_flash_attn.py:60-67), ALiBi adds slope[head] * (key - query position) to the
+// scaled score (the bias of the decode kernel, attention_kernels.cuh:286, at every query position).  A separate
+// instantiation: the plain causal path keeps its register count.
+template <typename T, bool KV8, bool IMG = false, bool OPTS = false>
 __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     T* __restrict__ out, const T* __restrict__ q, const void* __restrict__ k_cache_v,
     const void* __restrict__ v_cache_v, int num_heads, int num_kv_heads, float scale,
@@ -106,7 +112,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     const int* __restrict__ cu_seqlens_q, int max_num_blocks_per_seq, int q_blocks_per_seq,
     int64_t q_stride, int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride,
     const float* __restrict__ k_scale, const float* __restrict__ v_scale,
-    const int64_t* __restrict__ positions = nullptr, const T* __restrict__ cos_sin_cache = nullptr) {
+    const int64_t* __restrict__ positions = nullptr, const T* __restrict__ cos_sin_cache = nullptr,
+    int window = 0, float softcap = 0.f, const float* __restrict__ alibi_slopes = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [stage][K: 2 blocks | V: 2 blocks], a block = 4 KiB (scalar_t cache) or 2 KiB (fp8 cache)
   uint4* lds = reinterpret_cast<uint4*>(smem);
@@ -233,17 +240,30 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     }
   };
 
-  stage_issue(0, 0);
-  if (num_tiles > 1) stage_issue(1, 1);
+  // sliding window: no row of this workgroup sees a key below (first query position) - W + 1
+  int tile0 = 0;
+  if constexpr (OPTS) {
+    if (window > 0) tile0 = max(ctx + m0 - window + 1, 0) / kPfKvTile;
+  }
+  stage_issue(0, tile0);
+  if (tile0 + 1 < num_tiles) stage_issue(1, tile0 + 1);
 
-  const float sl2 = scale * 1.4426950408889634f;   // softmax scale in log2 units
+  // softmax scale in log2 units; with OPTS the scores are brought to scaled units first (cap / bias act there)
+  const float sl2 = (OPTS ? 1.0f : scale) * 1.4426950408889634f;
+  float slope = 0.f, cap_inv2 = 0.f;
+  int wave_first = 0;   // first key any row of this wave may see
+  if constexpr (OPTS) {
+    if (alibi_slopes != nullptr) slope = alibi_slopes[head];
+    if (softcap > 0.f) cap_inv2 = 2.0f * 1.4426950408889634f / softcap;   // tanh(x / cap) via 2^(2 x log2e / cap)
+    if (window > 0) wave_first = ctx + m0 + wave * 32 - window + 1;
+  }
   // every key <= this index is visible to EVERY query row of the wave (and is a real key)
   const int wave_limit_lo = min(ctx + m0 + wave * 32, seq_len - 1);
   // the wave's first query row decides which tiles it can skip entirely (causal)
   const int wave_q_hi = ctx + m0 + wave * 32 + 31;  // last key any row of this wave may see
 
   int cur = 0;   // ring slot of `tile`
-  for (int tile = 0; tile < num_tiles; ++tile) {
+  for (int tile = tile0; tile < num_tiles; ++tile) {
     // stage `tile` has landed once only the copies of the next stage are pending
     if (tile + 1 < num_tiles) lds_dma_wait<kCopies>();
     else lds_dma_wait<0>();
@@ -280,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
       }
       __syncthreads();
     }
-    if (t0 <= wave_q_hi) {
+    if (t0 <= wave_q_hi && (!OPTS || t0 + kPfKvTile > wave_first)) {
       const uint4* kbuf = lds + cur * kStageVec;
       const uint2* vbuf = reinterpret_cast<const uint2*>(lds + cur * kStageVec + 512);
       const char* sbuf = reinterpret_cast<const char*>(lds + cur * kStageVec);   // fp8 stage image
@@ -312,11 +332,34 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
       // only on tiles that reach past the wave's first visible-key limit (the diagonal / tail);
       // the accumulator rescale is skipped when no lane's running maximum moved (alpha == 1).
       uint4 pfrag[2];
-      const bool need_mask = (t0 + kPfKvTile - 1) > wave_limit_lo;
+      const bool need_mask = OPTS || (t0 + kPfKvTile - 1) > wave_limit_lo;
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
         float v[8];
-        if (need_mask) {
+        [[maybe_unused]] unsigned vis = 0xFFu;   // OPTS: which of the lane's 8 keys this row sees
+        if constexpr (OPTS) {
+          const int qpos = ctx + qrow[qt];
+          const int limit = min(qpos, seq_len - 1);
+          const int first = window > 0 ? qpos - window + 1 : 0;
+          vis = 0u;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int key = t0 + 16 * b + 4 * lr + j;
+              float sv = s[b][qt][j] * scale;
+              if (softcap > 0.f) {
+                // cap * tanh(sv / cap), tanh(x) = 1 - 2 / (e^(2x) + 1)
+                const float e = __builtin_amdgcn_exp2f(sv * cap_inv2);
+                sv = softcap * (1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f));
+              }
+              sv = fmaf(slope, (float)(key - qpos), sv);
+              const bool ok = key <= limit && key >= first;
+              vis |= ok ? (1u << (b * 4 + j)) : 0u;
+              v[b * 4 + j] = ok ? sv : kNegBig;
+            }
+          }
+        } else if (need_mask) {
           const int limit = min(ctx + qrow[qt], seq_len - 1);  // last visible key of this row
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
@@ -343,6 +386,12 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
         float p[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) p[i] = __builtin_amdgcn_exp2f(fmaf(v[i], sl2, mc));
+        if constexpr (OPTS) {
+          // a row whose window has not started yet has NO visible key in this stage: its running maximum is still
+          // the sentinel and 2^(sentinel - sentinel) would count every masked key as 1
+#pragma unroll
+          for (int i = 0; i < 8; ++i) p[i] = (vis >> i) & 1u ? p[i] : 0.f;
+        }
         const float psum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
         lrun[qt] = lrun[qt] * alpha + psum;
         if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
@@ -509,7 +558,8 @@ static int paged_prefill_impl(
     int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
     int64_t kv_head_stride, int dtype, int kv_cache_dtype, const float* k_scale,
     const float* v_scale, int sliding_window, float softcap, mi355x_stream stream, bool image,
-    const int64_t* positions = nullptr, const void* cos_sin_cache = nullptr) {
+    const int64_t* positions = nullptr, const void* cos_sin_cache = nullptr,
+    const float* alibi_slopes = nullptr) {
   MI355X_REQUIRE(sliding_window >= 0 && softcap >= 0.f, MI355X_EINVAL,
                  "paged_prefill_attention: sliding_window / softcap must be >= 0 (0 = off)");
   MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3,
@@ -529,15 +579,17 @@ static int paged_prefill_impl(
                      cu_seqlens_q,
                  MI355X_EINVAL, "paged_prefill_attention: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // sliding window / soft-cap: the general kernel only (correctness path; no BASELINE config uses them)
-  const bool fast = sliding_window == 0 && softcap == 0.f &&
-                    head_size == 128 && block_size == 16 && dtype != MI355X_F32 &&
+  // sliding window / soft-cap / ALiBi run on the OPTS instantiation of the MFMA kernel
+  const bool opts = sliding_window > 0 || softcap > 0.f || alibi_slopes != nullptr;
+  const bool fast = head_size == 128 && block_size == 16 && dtype != MI355X_F32 &&
                     q_stride % 8 == 0 && out_stride % 4 == 0 &&
                     ((reinterpret_cast<uintptr_t>(query) | reinterpret_cast<uintptr_t>(key_cache) |
                       reinterpret_cast<uintptr_t>(value_cache)) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
                     kv_block_stride % (kv8 ? 16 : 8) == 0 && kv_head_stride % (kv8 ? 16 : 8) == 0;
-  if (image && !(fast && (reinterpret_cast<uintptr_t>(out) & 15) == 0)) return 1;   // image form: fast path only
+  if (image && !(fast && !opts && (reinterpret_cast<uintptr_t>(out) & 15) == 0)) return 1;   // image form: plain fast path only
+  MI355X_REQUIRE(fast || alibi_slopes == nullptr, MI355X_EUNSUPPORTED,
+                 "paged_prefill_attention: alibi_slopes need head_size 128, block_size 16 and a 16-bit dtype");
   if (fast) {
     const int q_blocks = (max_query_len + kPfQTile - 1) / kPfQTile;
     dim3 grid(num_seqs * q_blocks * num_heads), block(256);
@@ -560,6 +612,24 @@ static int paged_prefill_impl(
                              static_cast<const scalar_t*>(cos_sin_cache));
         }
         return check_launch("paged_prefill_attention_image");
+      }
+      if (opts) {
+        if (kv8) {
+          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, false, true>), grid, block, smem, s,
+                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
+                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
+                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
+                             kv_block_stride, kv_head_stride, k_scale, v_scale, nullptr, nullptr,
+                             sliding_window, softcap, alibi_slopes);
+        } else {
+          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, false, false, true>), grid, block, smem, s,
+                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
+                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
+                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
+                             kv_block_stride, kv_head_stride, k_scale, v_scale, nullptr, nullptr,
+                             sliding_window, softcap, alibi_slopes);
+        }
+        return check_launch("paged_prefill_attention(opts)");
       }
       if (kv8) {
         hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true>), grid, block, smem, s,
@@ -614,6 +684,21 @@ extern "C" int mi355x_paged_prefill_attention(
                             block_size, scale, block_tables, seq_lens, cu_seqlens_q, max_query_len,
                             max_num_blocks_per_seq, q_stride, out_stride, kv_block_stride, kv_head_stride, dtype,
                             kv_cache_dtype, k_scale, v_scale, sliding_window, softcap, stream, false);
+}
+
+extern "C" int mi355x_paged_prefill_attention_alibi(
+    void* out, const void* query, const void* key_cache, const void* value_cache, int num_seqs,
+    int num_heads, int num_kv_heads, int head_size, int block_size, float scale,
+    const int* block_tables, const int* seq_lens, const int* cu_seqlens_q, int max_query_len,
+    int max_num_blocks_per_seq, int64_t q_stride, int64_t out_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, int dtype, int kv_cache_dtype, const float* k_scale,
+    const float* v_scale, int sliding_window, float softcap, const float* alibi_slopes,
+    mi355x_stream stream) {
+  return paged_prefill_impl(out, query, key_cache, value_cache, num_seqs, num_heads, num_kv_heads, head_size,
+                            block_size, scale, block_tables, seq_lens, cu_seqlens_q, max_query_len,
+                            max_num_blocks_per_seq, q_stride, out_stride, kv_block_stride, kv_head_stride, dtype,
+                            kv_cache_dtype, k_scale, v_scale, sliding_window, softcap, stream, false, nullptr,
+                            nullptr, alibi_slopes);
 }
 
 // returns 1 (no error) when the image form does not apply: run mi355x_paged_prefill_attention instead

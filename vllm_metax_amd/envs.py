@@ -10,6 +10,8 @@ environment_variables: dict[str, Callable[[], Any]] = {
     "MI355X_MAX_BATCHED_TOKENS": lambda: int(os.getenv("MI355X_MAX_BATCHED_TOKENS", "8192")),
     # keep a dequantised operand image of every int4 layer for the prefill GEMM (n*k*2 bytes per layer)
     "MI355X_PREPACK_WEIGHTS": lambda: os.getenv("MI355X_PREPACK_WEIGHTS", "0") == "1",
+    # register_patch(): route vLLM's Llama / Qwen2 MLP and decoder-layer forwards through the fused entry points
+    "MI355X_FUSED_LAYERS": lambda: os.getenv("MI355X_FUSED_LAYERS", "1") == "1",
     # fraction of the 288 GB HBM3E the KV pool may take (config sizing helper)
     "MI355X_KV_FRACTION": lambda: float(os.getenv("MI355X_KV_FRACTION", "0.9")),
 }
