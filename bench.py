@@ -83,6 +83,10 @@ def parse_args():
     ap.add_argument("--input-len", type=int, default=1024)
     ap.add_argument("--output-len", type=int, default=128)
     ap.add_argument("--chunk-seqs", type=int, default=8)
+    ap.add_argument("--chunk-tokens", type=int, default=0,
+                    help="chunked-prefill token budget per step (overrides --chunk-seqs): >= input-len: that many "
+                         "tokens of whole sequences per chunk; smaller: every prompt is prefilled in pieces of this "
+                         "many tokens against its own cached context (mid-size GEMMs, context > 0 attention)")
     ap.add_argument("--parallelism", default=None, choices=["dp", "tp"],
                     help="N > 1: tp (default) = one model sharded over the N GPUs (column/row-parallel "
                          "GEMMs, RCCL all-reduce after o_proj / down_proj, strong scaling); dp = one model "
@@ -277,10 +281,12 @@ def run_job(model, tokens, args, timer=None, ttft=None):
     """One whole job.  Returns nothing; `ttft` (list) receives per-sequence first-token events."""
     B, Lin, Lout = args.batch, args.input_len, args.output_len
     first = torch.empty(B, dtype=torch.int64, device=model.device)
+    piece = args.chunk_tokens if 0 < args.chunk_tokens < Lin else Lin
     for c0 in range(0, B, args.chunk_seqs):
         ids = list(range(c0, min(c0 + args.chunk_seqs, B)))
-        model.cfg_ctx_for_cost = 0
-        nxt = model.prefill(tokens[ids[0]:ids[-1] + 1], ids, 0)
+        for ctx in range(0, Lin, piece):       # (one pass unless --chunk-tokens < input-len)
+            model.cfg_ctx_for_cost = ctx
+            nxt = model.prefill(tokens[ids[0]:ids[-1] + 1, ctx:ctx + piece], ids, ctx)
         first[ids[0]:ids[-1] + 1] = nxt
         if ttft is not None:
             ev = torch.cuda.Event(enable_timing=True)
@@ -524,7 +530,7 @@ def no_prepack_entry(model, args, timer: EventTimer):
     image-based GEMM so that the line shows what the image buys."""
     from vllm_metax_amd import _custom_ops as ops
     L = model.layers[0]
-    m = args.chunk_seqs * args.input_len
+    m = args.chunk_seqs * min(args.input_len, args.chunk_tokens or args.input_len)
     tot_ms, tot_flops, n = 0.0, 0.0, 0
     for q in (L.qkv, L.o, L.gate_up, L.down):
         if q.quant not in ("awq", "gptq"):
@@ -584,6 +590,8 @@ def make_cfg(args, tp_degree, rank, model_name=None, quant=None):
 
 def main():
     args = parse_args()
+    if args.chunk_tokens:
+        args.chunk_seqs = max(1, args.chunk_tokens // args.input_len)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))      # (before any GPU call in this process)
     rank = int(os.environ.get("RANK", "0"))
@@ -815,8 +823,10 @@ def main():
         "dtype": {"fp8": "fp8", "int8": "int8"}.get(quant, "bf16"),
         "data": "synthetic",
         "config": {"workload": f"{cfg.name}-{quant} {WEIGHT_FORMAT.get(quant, quant)}: prefill {args.batch}x{args.input_len} "
-                               f"in chunks of {args.chunk_seqs} seqs + {args.output_len - 1} graph-replayed "
-                               f"decode steps (1 step = 1 whole job)",
+                               f"in chunks of {args.chunk_seqs} seqs"
+                               + (f" x {args.chunk_tokens} tokens (context > 0 from the second piece on)"
+                                  if 0 < args.chunk_tokens < args.input_len else "")
+                               + f" + {args.output_len - 1} graph-replayed decode steps (1 step = 1 whole job)",
                    "batch": args.batch, "global_batch": args.batch * replicas,
                    "input_len": args.input_len, "output_len": args.output_len,
                    "parallelism": par, "kv_block_size": 16,

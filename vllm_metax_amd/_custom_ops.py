@@ -563,7 +563,7 @@ def _dq_scratch(m: int, n: int, k: int, device) -> Optional[torch.Tensor]:
     if m <= 64:
         need = m_pad * k * 2                    # decode: packed activations only
     elif m < 1024:
-        return None
+        need = 8 * 128 * n * 4                  # 64 < m < 1024: fp32 split-K slabs of one 128-row pass
     else:
         need = (n + m_pad) * k * 2              # prefill: packed weights + packed activations
     return _grow(_DQ_SCRATCH, device, need, torch.uint8)

@@ -545,13 +545,38 @@ static int run_gemm_t(const GemmArgs& g, int dtype) {
     int rc = w4a16_gemm_unfused_dispatch(g, dtype);
     if (rc != 1) return rc;  // 1 = no scratch / shape not handled: fall through to the fused kernel
   }
-  if (g.m >= 128) {
-    int rc = w4a16_gemm_large_m_dispatch(g, dtype);
-    if (rc != 1) return rc;  // 1 = shape not handled by the large-M kernel
+  // 64 < m < 1024 (chunked-prefill budgets of a few hundred tokens, mixed batches): passes of up to 128 rows
+  // through the stripe kernel, split-K slabs in the fp32 workspace or, when the caller gave none, in the scratch
+  // of the prefill path — measured (scripts/bench_gemm.py, Llama-3-8B layer): 1040-1130 us per layer with the
+  // 128 x 256-tile kernel below (16-48 workgroups for the narrow projections) against ~90 us per 128-row pass.
+  GemmArgs gm = g;
+  if (g.m > 64 && gm.ws == nullptr && g.dq_ws != nullptr && (reinterpret_cast<uintptr_t>(g.dq_ws) & 15) == 0) {
+    gm.ws = static_cast<float*>(g.dq_ws);
+    gm.ws_elems = g.dq_ws_bytes / 4;
   }
-  for (int row0 = 0; row0 < g.m; row0 += 64) {
-    const int rows = (g.m - row0) < 64 ? (g.m - row0) : 64;
-    int rc = w4a16_gemm_stripe_dispatch(g, dtype, row0, rows);
+  const int pass = g.m > 64 ? 128 : 64;
+  bool stripe_ok = true;
+  if (g.m >= 128) {
+    // probe: does the stripe path take this shape at all?  (otherwise the tile kernel below serves it)
+    stripe_ok = g.k % 128 == 0 && g.n % 64 == 0 && (g.group % 128 == 0 || (g.group >= 32 && 128 % g.group == 0));
+    if (!stripe_ok) {
+      int rc = w4a16_gemm_large_m_dispatch(g, dtype);
+      if (rc != 1) return rc;  // 1 = shape not handled by the large-M kernel
+    }
+  }
+  for (int row0 = 0; row0 < g.m; row0 += pass) {
+    const int rows = (g.m - row0) < pass ? (g.m - row0) : pass;
+    int rc = w4a16_gemm_stripe_dispatch(gm, dtype, row0, rows);
+    if (rc == 1 && rows > 64) {       // not a stripe shape after all: two 64-row halves on the general kernels
+      for (int r1 = row0; r1 < row0 + rows; r1 += 64) {
+        const int rr = (row0 + rows - r1) < 64 ? (row0 + rows - r1) : 64;
+        rc = w4a16_gemm_stripe_dispatch(gm, dtype, r1, rr);
+        if (rc == 1)
+          rc = g.zmode == kZeroAwq ? launch_small_m<T, kZeroAwq>(gm, r1, rr) : launch_small_m<T, kZeroGptq>(gm, r1, rr);
+        if (rc) return rc;
+      }
+      continue;
+    }
     if (rc != 1) {
       if (rc) return rc;
       continue;

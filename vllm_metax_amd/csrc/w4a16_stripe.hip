@@ -586,12 +586,13 @@ static StripePlan plan_stripe(int rows, int n, int k, int64_t ws_elems, int bk) 
     }
   }
   const int mt = (rows + 15) / 16;
-  const int mtt = mt <= 1 ? 1 : (mt <= 2 ? 2 : 4);
+  const int mtt = mt <= 1 ? 1 : (mt <= 2 ? 2 : (mt <= 4 ? 4 : 8));
   const int stages = k / kStBK;
   const double wbytes = (double)n * k / 2;
   StripePlan best{0, 1, stages, 1e30};
   for (int nw = 2; nw <= 4; nw += 2) {
     if (bk == 256 && nw != 2) continue;   // (16 waves: 2 column waves x 8 K waves only)
+    if (mtt == 8 && nw != 2) continue;    // (128-row passes: 256-column stripes would need > 160 KiB of rings)
     const int bn = 64 * nw;
     const int stripes = (n + bn - 1) / bn;
     const double fill = (64.0 * bn + mtt * 4096.0) / 70e3;
@@ -655,7 +656,11 @@ static int launch_stripe_mt(const GemmArgs& g, const T* a, T* c, int rows, const
   const int mt = (rows + 15) / 16;
   if (mt <= 1) return launch_stripe_nw<T, 1, ZMODE, SETS>(g, a, c, rows, p, wv);
   if (mt <= 2) return launch_stripe_nw<T, 2, ZMODE, SETS>(g, a, c, rows, p, wv);
-  return launch_stripe_nw<T, 4, ZMODE, SETS>(g, a, c, rows, p, wv);
+  if (mt <= 4) return launch_stripe_nw<T, 4, ZMODE, SETS>(g, a, c, rows, p, wv);
+  // 65 .. 128 rows per pass (chunked-prefill / mixed-batch sizes, 64 < M < 1024): the dequantised fragment of a
+  // wave feeds 8 row tiles — per 128-k stage 32 MFMAs (512 matrix-pipe cycles) beside the same ~100 dequant VALU,
+  // so a 128-row pass costs about what a 64-row pass does
+  return launch_stripe_nw<T, 8, ZMODE, SETS>(g, a, c, rows, p, wv);
 }
 
 // waves per workgroup: 16 (stages of 256 k, four waves per SIMD) for long unsplit K loops.  Per 128 k the
@@ -690,7 +695,7 @@ static int stripe_sets(int group, int bk) {
 // returns 1 when the shape / scratch is not one this path handles (caller falls back)
 template <typename T>
 static int run_stripe(const GemmArgs& g, int row0, int rows) {
-  if (rows > 64 || g.k % 128 != 0 || g.n % 64 != 0 || g.n < 64) return 1;
+  if (rows > 128 || g.k % 128 != 0 || g.n % 64 != 0 || g.n < 64) return 1;
   if ((reinterpret_cast<uintptr_t>(g.qw) & 15) || (reinterpret_cast<uintptr_t>(g.scales) & 15) ||
       (reinterpret_cast<uintptr_t>(g.qz) & 15))
     return 1;
@@ -698,6 +703,7 @@ static int run_stripe(const GemmArgs& g, int row0, int rows) {
   T* c = static_cast<T*>(g.c) + (int64_t)row0 * g.n;
   int rc;
   StripePlan p = plan_stripe(rows, g.n, g.k, g.ws ? g.ws_elems : 0, 128);
+  if (rows > 64 && g.fuse_silu) return 1;
   if (p.nw == 0) return 1;
   const int wv = p.nw == 2 ? stripe_waves(g.k, g.group, p.sk) : 8;
   const int bk = 16 * wv;
