@@ -46,13 +46,9 @@ constexpr int kPaScratchBytes = 256;  // red[GT <= 4][16] floats
 // L2 / MALL is worth 10 % (64 seqs x ctx 1088, v1: 54.3 -> 48.5 us, fp8 cache 34.8 -> 30.5 us;
 // profiles/r02_attn_ab2.txt).  -DPA_NO_NT builds the default-policy variant of that comparison.
 __device__ __forceinline__ uint4 ld_kv16(const void* p) {
-#ifndef PA_NO_NT
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
   return make_uint4(v.x, v.y, v.z, v.w);
-#else
-  return *reinterpret_cast<const uint4*>(p);
-#endif
 }
 
 // Block-wide max / sum of N values at once: ONE pair of barriers for all of them (the softmax of the

@@ -24,8 +24,8 @@
 //     stream; partial tiles go to fp32 slabs ws[split][M][N] with plain stores and one small
 //     kernel adds the slabs in split order and rounds to T (deterministic, no atomics: float
 //     atomics run at ~1.3 TB/s chip-wide, plain stores at ~6).
-//   * -DSTRIPE_ABLATE_COMPUTE / _DMA / STRIPE_NO_A / STRIPE_NO_NT / STRIPE_DEEP are the compile-time
-//     ablations behind the numbers in the notes (scripts/build_variant.sh); never set in the build.
+//   * -DSTRIPE_STAMP is the one compile-time switch left (in-kernel s_memtime stamps, scripts/stamp_stripe.py);
+//     the ablation arms behind the numbers in profiles/r0[12]_decode_gemm_notes.md were removed in round 3.
 #include <cstdio>
 #include <cstdlib>
 
@@ -33,9 +33,7 @@
 
 namespace mi355x {
 
-#ifndef STRIPE_T256
-#define STRIPE_T256 1.25   // cost-model time of a 256-k stage (16 waves) relative to a 128-k stage (8 waves)
-#endif
+constexpr double STRIPE_T256 = 1.25;   // cost-model time of a 256-k stage relative to a 128-k stage (bk = 256 plans)
 
 // WV = waves per workgroup: 8 (stages of 128 k) or 16 (stages of 256 k, 4 waves per SIMD).  A wave's own
 // instruction stream — ~120 VALU at one issue per 6-8 cycles, ~100 SALU, the LDS and copy-issue latencies —
@@ -60,18 +58,9 @@ struct StripeCfg {
   static constexpr int A_BYTES = A_IMG_BYTES + SETS * SET_BYTES;  // A-ring slot: images + sets
   // ring depths: the weight stream comes from HBM (~2-3 us under load) and needs >= 48 KiB in
   // flight per CU; activations / scales come from L2 and need two stages ahead.
-#ifdef STRIPE_DEEP
-  static constexpr int W_DEPTH = NW == 2 ? 8 : 5;
+  static constexpr int W_DEPTH = 3;
   static constexpr int A_DEPTH = 3;
   static constexpr int WAVES_PER_SIMD = WV / 4;
-#else
-#ifndef STRIPE_AD
-#define STRIPE_AD 3
-#endif
-  static constexpr int W_DEPTH = 3;
-  static constexpr int A_DEPTH = STRIPE_AD;
-  static constexpr int WAVES_PER_SIMD = WV / 4;
-#endif
   static constexpr int W_COPIES = NW;            // per weight-loader wave (waves 0-3) and stage
   static constexpr int A_COPIES = MT + 1;        // per activation-loader wave (4-7): images + one set
   static constexpr int A_RING = 0;
@@ -83,11 +72,7 @@ struct StripeCfg {
 
 // streamed-once variant of lds_dma16 (nt: do not keep the line in L2 for somebody else)
 __device__ __forceinline__ void lds_dma16_nt(const void* gptr, uint32_t lds_base) {
-#ifdef STRIPE_NO_NT
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-#else
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt"
-#endif
                :
                : "v"(gptr), "s"(lds_base)
                : "memory");
@@ -202,18 +187,12 @@ __global__ __launch_bounds__((StripeCfg<MT, NW, SETS, WV>::THREADS)) void w4a16_
   }
 
   auto issue_w = [&](int slot, int stage) {
-#ifdef STRIPE_ABLATE_DMA
-    return;
-#endif
     const uint32_t sb = lds_base + Cfg::W_RING + slot * Cfg::W_BYTES + lw * Cfg::W_COPIES * 1024;
 #pragma unroll
     for (int j = 0; j < Cfg::W_COPIES; ++j)
       lds_dma16_s_nt(qw + (int64_t)stage * (kStBK / 8) * n, w_off[j], sb + j * 1024);
   };
   auto issue_a = [&](int slot, int stage) {
-#if defined(STRIPE_ABLATE_DMA) || defined(STRIPE_NO_A)
-    return;
-#endif
     const uint32_t sb = lds_base + Cfg::A_RING + slot * Cfg::A_BYTES;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -246,7 +225,6 @@ __global__ __launch_bounds__((StripeCfg<MT, NW, SETS, WV>::THREADS)) void w4a16_
   const int colw = 64 * wn + 4 * lc;       // first of this lane's 4 columns inside the stripe
   const int ncol = gcol(colw);
   int cur_w = 0, cur_a = 0;                // ring slots of stage `it`
-#ifndef STRIPE_NO_PINGPONG
   // The two waves of a SIMD (w and w + 4) run the loop half an iteration apart, as in the prefill GEMM
   // (w4a16_unfused.hip): an iteration is {memory cluster: LDS reads of the stage's operands, copies of a
   // later stage, own copies of stage it+1 retired} barrier {dequant + MFMA on registers} barrier, and waves
@@ -320,7 +298,6 @@ __global__ __launch_bounds__((StripeCfg<MT, NW, SETS, WV>::THREADS)) void w4a16_
     __builtin_amdgcn_s_barrier();
     ST_T(st2);
     __builtin_amdgcn_sched_barrier(0);
-#ifndef STRIPE_ABLATE_COMPUTE
     // Software pipeline over the 4*KS_PER_WAVE packed words of the stage: the MFMAs of word j
     // are issued between the dequant VALU of word j+1 (a lone wave issues a VALU op every ~8
     // cycles and an MFMA occupies the matrix pipe for 16: back to back they do not overlap).
@@ -360,7 +337,6 @@ __global__ __launch_bounds__((StripeCfg<MT, NW, SETS, WV>::THREADS)) void w4a16_
       }
       bf_cur = bf_nxt;
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
     ST_T(st3);
     __builtin_amdgcn_s_barrier();
@@ -384,94 +360,6 @@ __global__ __launch_bounds__((StripeCfg<MT, NW, SETS, WV>::THREADS)) void w4a16_
   }
 #endif
   if (w_loader) __builtin_amdgcn_s_barrier();
-#else
-  for (int it = 0; it < nst; ++it) {
-    // stage `it` has landed once only the copies of the stages issued after it are pending
-    if (w_loader) {
-      if (it + Cfg::W_DEPTH - 2 < nst) lds_dma_wait<Cfg::W_COPIES * (Cfg::W_DEPTH - 2)>();
-      else lds_dma_wait<0>();
-    } else {
-      if (it + Cfg::A_DEPTH - 2 < nst) lds_dma_wait<Cfg::A_COPIES * (Cfg::A_DEPTH - 2)>();
-      else lds_dma_wait<0>();
-    }
-    __syncthreads();   // stage `it` is complete in LDS; everybody is done with stage it-1
-    // this wave's operands of the stage: LDS reads go out first, the copies of a later stage
-    // are issued while they are in flight
-    const char* ab = smem + Cfg::A_RING + cur_a * Cfg::A_BYTES;
-    const char* wb = smem + Cfg::W_RING + cur_w * Cfg::W_BYTES;
-    uint2 scq[Cfg::KS_PER_WAVE];
-    uint32_t zq[Cfg::KS_PER_WAVE];
-    uint4 wq[Cfg::KS_PER_WAVE];
-    uint4 af[Cfg::KS_PER_WAVE][MT];
-#pragma unroll
-    for (int q = 0; q < Cfg::KS_PER_WAVE; ++q) {
-      const int ks = wk * Cfg::KS_PER_WAVE + q;
-      const int set = ks / (Cfg::KSTEPS / SETS);
-      const char* setp = ab + Cfg::A_IMG_BYTES + set * Cfg::SET_BYTES;
-      scq[q] = *reinterpret_cast<const uint2*>(setp + colw * 2);
-      zq[q] = *reinterpret_cast<const uint32_t*>(setp + 16 * Cfg::SC_LANES + (colw >> 3) * 4);
-      wq[q] = *reinterpret_cast<const uint4*>(wb + (4 * ks + lr) * Cfg::W_ROW_BYTES + colw * 4);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        af[q][i] = *reinterpret_cast<const uint4*>(ab + (ks >> 2) * Cfg::A_HALF_BYTES + i * 4096 + a_rd +
-                                                   (((ks & 3) ^ (lc >> 2)) << 6));
-    }
-    if (w_loader) {
-      const int nxt = it + Cfg::W_DEPTH - 1;   // goes into the slot stage it-1 just vacated
-      int slot = cur_w + Cfg::W_DEPTH - 1;
-      slot = slot >= Cfg::W_DEPTH ? slot - Cfg::W_DEPTH : slot;
-      if (nxt < nst) issue_w(slot, stage_of(nxt));
-    } else {
-      const int nxt = it + Cfg::A_DEPTH - 1;
-      int slot = cur_a + Cfg::A_DEPTH - 1;
-      slot = slot >= Cfg::A_DEPTH ? slot - Cfg::A_DEPTH : slot;
-      if (nxt < nst) issue_a(slot, stage_of(nxt));
-    }
-#ifndef STRIPE_ABLATE_COMPUTE
-    // Software pipeline over the 4*KS_PER_WAVE packed words of the stage: the MFMAs of word j
-    // are issued between the dequant VALU of word j+1 (a lone wave issues a VALU op every ~8
-    // cycles and an MFMA occupies the matrix pipe for 16: back to back they do not overlap).
-    constexpr int NWORDS = 4 * Cfg::KS_PER_WAVE;
-    float scf[Cfg::KS_PER_WAVE][4], zsf[Cfg::KS_PER_WAVE][4];
-#pragma unroll
-    for (int q = 0; q < Cfg::KS_PER_WAVE; ++q) {
-      T sct[4];
-      *reinterpret_cast<uint2*>(sct) = scq[q];
-      float zp[4];
-      unpack_zeros4<ZMODE>(zq[q], ncol, zp);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        scf[q][t] = to_f32(sct[t]);
-        zsf[q][t] = -zp[t] * scf[q][t];
-      }
-    }
-    auto word_of = [&](int j) {
-      const int q = j >> 2, t = j & 3;
-      return t == 0 ? wq[q].x : (t == 1 ? wq[q].y : (t == 2 ? wq[q].z : wq[q].w));
-    };
-    uint4 bf_cur = dequant_word<T>(word_of(0), scf[0][0], zsf[0][0]);
-#pragma unroll
-    for (int j = 0; j < NWORDS; ++j) {
-      const int q = j >> 2, t = j & 3;
-      uint4 bf_nxt = bf_cur;
-      if (j + 1 < NWORDS) bf_nxt = dequant_word<T>(word_of(j + 1), scf[(j + 1) >> 2][(j + 1) & 3], zsf[(j + 1) >> 2][(j + 1) & 3]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][t] = Mfma<T>::run(af[q][i], bf_cur, acc[i][t]);
-      if (j + 1 < NWORDS) {
-        // interleave: MT groups of {1 MFMA, ceil(19/MT) VALU}
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, (19 + MT - 1) / MT, 0);
-        }
-      }
-      bf_cur = bf_nxt;
-    }
-#endif
-    cur_w = cur_w + 1 == Cfg::W_DEPTH ? 0 : cur_w + 1;
-    cur_a = cur_a + 1 == Cfg::A_DEPTH ? 0 : cur_a + 1;
-  }
-#endif
 
   // ---- add the KW K-waves of each column wave through LDS (the rings are dead now): a binary tree, in
   // every round the upper half of the live K-waves hands its tiles to the lower half (fixed order) ----
@@ -643,9 +531,6 @@ static int launch_stripe_cfg(const GemmArgs& g, const T* a, T* c, int rows, cons
 
 template <typename T, int MT, int ZMODE, int SETS>
 static int launch_stripe_nw(const GemmArgs& g, const T* a, T* c, int rows, const StripePlan& p, int wv) {
-#ifdef STRIPE_WV16
-  if (wv == 16) return launch_stripe_cfg<T, MT, 2, ZMODE, SETS, false, 16>(g, a, c, rows, p);
-#endif
   (void)wv;
   if (p.nw == 2) return launch_stripe_cfg<T, MT, 2, ZMODE, SETS>(g, a, c, rows, p);
   return launch_stripe_cfg<T, MT, 4, ZMODE, SETS>(g, a, c, rows, p);
@@ -663,27 +548,10 @@ static int launch_stripe_mt(const GemmArgs& g, const T* a, T* c, int rows, const
   return launch_stripe_nw<T, 8, ZMODE, SETS>(g, a, c, rows, p, wv);
 }
 
-// waves per workgroup: 16 (stages of 256 k, four waves per SIMD) for long unsplit K loops.  Per 128 k the
-// 16-wave loop takes ~1300 cycles against ~1560 (scripts/stamp_stripe.py), but its prologue (two 48-KiB
-// stages) and its K-wave reduction (8 tiles instead of 4 through LDS) cost ~4.5k cycles more: it pays
-// from ~12 stages of 256 k per workgroup on, i.e. for gate_up, not for the K-split qkv / o / down launches.
-static int stripe_waves(int k, int group, int sk) {
-  static const int forced = [] {
-    const char* e = getenv("MI355X_STRIPE_WV");   // kernel experiments: 8 or 16
-    return e ? atoi(e) : 0;
-  }();
-#ifdef STRIPE_WV16
-  const bool ok16 = k % 256 == 0 && (group % 256 == 0 || group == 128 || group == 64);
-  if (forced == 8 || !ok16) return 8;
-  if (forced == 16) return 16;
-  return sk == 1 && k / 256 >= 12 ? 16 : 8;
-#else
-  // The 16-wave instantiations are compiled only with -DSTRIPE_WV16: with the rule above bench.py measures
-  // 5993 tokens/s against 5994 with 8 waves everywhere (gate_up alone 31.5-33.7 us vs 32.3-35.0).
-  (void)forced; (void)k; (void)group; (void)sk;
-  return 8;
-#endif
-}
+// waves per workgroup: 8.  (A 16-wave variant — stages of 256 k, four waves per SIMD — reached the vector-issue-port
+// bound in its loop, ~1300 cycles per 128 k against ~1560, and gave it back in its prologue and 8-tile K-wave
+// reduction: bench.py 5993 vs 5994 tokens/s, profiles/r02_decode_gemm_notes.md; removed from the source in round 3.)
+static int stripe_waves(int, int, int) { return 8; }
 // scale / zero sets per stage of bk k; 0: not a layout this kernel handles
 static int stripe_sets(int group, int bk) {
   if (group % bk == 0) return 1;
@@ -745,13 +613,7 @@ static int run_stripe_silu(const GemmArgs& g) {
   T* c = static_cast<T*>(g.c);
   const StripePlan p{2, 1, g.k / bk, 0.0};
   const int mt = (g.m + 15) / 16;
-#ifdef STRIPE_WV16
-#define STRIPE_SW(MTV, SETSV)                                                                  \
-  (wv == 16 ? launch_stripe_cfg<T, MTV, 2, kZeroAwq, SETSV, true, 16>(g, a, c, g.m, p)          \
-            : launch_stripe_cfg<T, MTV, 2, kZeroAwq, SETSV, true, 8>(g, a, c, g.m, p))
-#else
 #define STRIPE_SW(MTV, SETSV) launch_stripe_cfg<T, MTV, 2, kZeroAwq, SETSV, true, 8>(g, a, c, g.m, p)
-#endif
 #define STRIPE_S(MTV) (sets == 1 ? STRIPE_SW(MTV, 1) : (sets == 2 ? STRIPE_SW(MTV, 2) : STRIPE_SW(MTV, 4)))
   if (mt <= 1) return STRIPE_S(1);
   if (mt <= 2) return STRIPE_S(2);

@@ -109,22 +109,11 @@ __global__ __launch_bounds__(256) void w8_dequant_pack_kernel(
 constexpr int kUfBM = 256;
 constexpr int kUfBN = 256;
 constexpr int kUfBK = 32;
-#ifndef UF_STAGES
-#define UF_STAGES 4
-#endif
-#ifndef UF_PP_ORDER
-#define UF_PP_ORDER 1   // 0: copies, then fragment reads; 1: reads, then copies; 2: copies inside the MFMA cluster
-#endif
-#ifndef UF_PP_LGKM_AFTER
-#define UF_PP_LGKM_AFTER 0
-#endif
-constexpr int kUfStages = UF_STAGES;
-#ifdef UF_DIST
-constexpr int kUfDist = UF_DIST;             // stages between a copy's issue and its first read
-#else
-constexpr int kUfDist = kUfStages - 1;
-#endif
-static_assert(kUfDist <= kUfStages - 1 - UF_PP_LGKM_AFTER, "a ring slot is re-staged only after its reads retired");
+// (Round-2 ablation arms — copy placement orders 0 / 2, lgkmcnt after the barrier, shorter issue distance, the
+//  in-phase round-1 loop, the MFMA-less fill-rate build — were measured in profiles/r02_gemm_pingpong_ab.txt and
+//  removed from the source in round 3; what is kept is the one schedule that won.)
+constexpr int kUfStages = 4;
+constexpr int kUfDist = kUfStages - 1;       // stages between a copy's issue and its first read
 constexpr int kUfThreads = 512;
 
 // SILU = true: the GEMM is a gate_up projection (n = 2 * ffn, gate columns first) and the epilogue
@@ -157,10 +146,7 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   // (a 32 x 1 strip re-streams every A panel from HBM/MALL for every column block).
   int mb, nb;
   {
-#ifndef UF_GM
-#define UF_GM 8
-#endif
-    constexpr int GM = UF_GM;
+    constexpr int GM = 8;
     const int num_n_blocks = num_tiles / num_m_blocks;
     const int group = tile / (GM * num_n_blocks);
     const int first_m = group * GM;
@@ -207,12 +193,6 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     }
   };
   constexpr int kPerStage = 4;  // copies one wave issues per stage
-  auto stage_one = [&](int buf, int kt, int c) {   // copy c (0..3) of stage()
-    const int i = c >> 1;
-    const int p = wave * 2 + i;
-    if (c & 1) lds_dma16(b_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + kBOff + p * 64) * 16);
-    else lds_dma16(a_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + p * 64) * 16);
-  };
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -223,16 +203,11 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
 
 #pragma unroll
   for (int s = 0; s < kUfDist; ++s) {
-#if !defined(UF_NO_PINGPONG) && UF_PP_ORDER == 2
-    stage(s, s < ktiles ? s : ktiles - 1);   // constant copy count per stage: constant wait counts
-#else
     if (s < ktiles) stage(s, s);
-#endif
   }
 
   const int frag = frag_swz(lr, lc);  // this lane's slot inside a piece
   int cur = 0;                        // ring slot of stage kt
-#ifndef UF_NO_PINGPONG   // (-DUF_NO_PINGPONG: the round-1 loop, all 8 waves in phase, one barrier per stage)
   // Two wave groups (waves 0-3 / 4-7: one of each per SIMD) run the same loop half an iteration
   // apart: an iteration is {memory cluster: copies of stage kt+S-1, the 12 fragment reads of stage
   // kt} barrier {32 MFMAs} barrier, and group 1 enters the loop one barrier late, so that while one
@@ -242,21 +217,14 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   //    cluster of stage k (epochs 2k / 2k+1); the first read of stage k+1 is in epoch 2k+2.
   //  * WAR: slot (k-1) % S is re-staged in the memory cluster of stage k (epoch >= 2k); its last
   //    reads (group 1, epoch 2k-1) were retired by the lgkmcnt(0) in front of that epoch's barrier.
-#if UF_PP_ORDER == 2
-  lds_dma_wait<kPerStage * (kUfDist - 1)>();                            // own copies of stage 0
-#else
   if (ktiles >= kUfDist) lds_dma_wait<kPerStage * (kUfDist - 1)>();   // own copies of stage 0
   else lds_dma_wait<0>();
-#endif
   __syncthreads();
   if (wave >= 4) __builtin_amdgcn_s_barrier();
   for (int kt = 0; kt < ktiles; ++kt) {
     const int nxt = kt + kUfDist;
     int slot = cur + kUfDist;
     slot = slot >= kUfStages ? slot - kUfStages : slot;
-#if UF_PP_ORDER == 0
-    if (nxt < ktiles) stage(slot, nxt);
-#endif
     const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
     const uint4* bbuf = lds + cur * kStage + kBOff + (SILU ? wn * 2 : wn * 4) * 64 + frag;
     uint4 bf[4], af[8];
@@ -264,39 +232,19 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     for (int t = 0; t < 4; ++t) bf[t] = bbuf[(SILU ? (t < 2 ? t : 6 + t) : t) * 64];
 #pragma unroll
     for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
-#if UF_PP_ORDER == 1
     __builtin_amdgcn_sched_barrier(0);
     if (nxt < ktiles) stage(slot, nxt);
-#endif
-#if UF_PP_ORDER == 2
-    lds_dma_wait<kPerStage * (kUfDist - 2)>();   // own copies of stage kt+1 (stage kt+D goes out below)
-#else
     if (nxt < ktiles) lds_dma_wait<kPerStage * (kUfDist - 1)>();   // own copies of stage kt+1
     else lds_dma_wait<0>();
-#endif
-#if !UF_PP_LGKM_AFTER
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
-#if UF_PP_LGKM_AFTER
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[i][t] = Mfma<T>::run(af[i], bf[t], acc[i][t]);
-#if UF_PP_ORDER == 2
-      // the copies of stage kt + D ride in the MFMA cluster, one every 8 MFMAs (an MFMA holds the
-      // SIMD's vector issue for half of its 16 cycles; the partner's memory cluster is then reads only)
-      if (!(i & 1)) {
-        __builtin_amdgcn_sched_barrier(0);
-        stage_one(slot, nxt < ktiles ? nxt : ktiles - 1, i >> 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
     }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
@@ -304,44 +252,7 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     __builtin_amdgcn_sched_barrier(0);
     cur = cur + 1 == kUfStages ? 0 : cur + 1;
   }
-#if UF_PP_ORDER == 2
-  lds_dma_wait<0>();   // (the clamped copies of the last iterations still target the ring)
-#endif
   if (wave < 4) __builtin_amdgcn_s_barrier();
-#else
-  for (int kt = 0; kt < ktiles; ++kt) {
-    // stage kt has landed once at most the copies of the stages issued after it are pending
-    if (kt + kUfStages - 2 < ktiles) lds_dma_wait<kPerStage * (kUfStages - 2)>();
-    else lds_dma_wait<0>();
-    __syncthreads();  // everybody's share of stage kt is in LDS; all reads of stage kt-1 are done
-    {
-      const int nxt = kt + kUfStages - 1;  // goes into the slot stage kt-1 just vacated
-      int slot = cur + kUfStages - 1;
-      slot = slot >= kUfStages ? slot - kUfStages : slot;
-      if (nxt < ktiles) stage(slot, nxt);
-    }
-    const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
-    // SILU: pieces 2wn, 2wn+1 (gate) and 8+2wn, 8+2wn+1 (up); else pieces 4wn .. 4wn+3
-    const uint4* bbuf = lds + cur * kStage + kBOff + (SILU ? wn * 2 : wn * 4) * 64 + frag;
-    // all 12 fragment reads of the stage go out before the first MFMA (the scheduler would
-    // otherwise pair each A read with its 4 MFMAs and expose the LDS latency 8 times per stage)
-#ifndef UF_ABLATE_MFMA   // (-DUF_ABLATE_MFMA: copies + barriers only, to measure the fill rate)
-    uint4 bf[4], af[8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) bf[t] = bbuf[(SILU ? (t < 2 ? t : 6 + t) : t) * 64];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[i][t] = Mfma<T>::run(af[i], bf[t], acc[i][t]);
-    }
-#endif
-    cur = cur + 1 == kUfStages ? 0 : cur + 1;
-  }
-
-#endif
 
   // ---- epilogue: lane holds 4 consecutive columns per (i, j) --------------------------------
   if constexpr (MODE == 2) {
