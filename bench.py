@@ -245,6 +245,8 @@ def instrument(model, timer: EventTimer):
          (0.0, float(inp.numel() * inp.element_size() * (3 if res is not None else 1) + out.numel())))
     wrap("dynamic_per_token_scaled_fp8_quant",
          lambda out, inp, sc, ub=None: (0.0, float(inp.numel() * inp.element_size() + out.numel())))
+    wrap("silu_and_mul_per_token_quant", lambda inp: (0.0, float(inp.numel() * inp.element_size() + inp.numel() // 2)),
+         record_as="silu_and_mul")
     wrap("greedy_advance", lambda logits, *a, **k: (0.0, float(logits.numel() * logits.element_size())))
     wrap("rotary_reshape_and_cache",
          lambda pos, key, value, kc, *a, **k: (0.0, 2.0 * key.numel() * (2 + kc.element_size())),

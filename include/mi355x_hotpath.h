@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 4   /* 4: + paged_prefill_attention_alibi (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
+#define MI355X_ABI_VERSION 4   /* 4: + paged_prefill_attention_alibi, silu_and_mul_per_token_quant (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
                                 * 2 was BREAKING (kv_cache_dtype / k_scale / v_scale inserted before `stream` in reshape_and_cache*,
                                 * paged_attention_v1/_v2, paged_prefill_attention): a binding must refuse a library whose
                                 * mi355x_abi_version() differs from the version it was written for (vllm_metax_amd/_abi.py does) */
@@ -407,6 +407,13 @@ int mi355x_merge_attn_states(void* output, float* output_lse, const void* prefix
                              const float* prefix_lse, const void* suffix_output,
                              const float* suffix_lse, int num_tokens, int num_heads, int head_size,
                              int dtype, mi355x_stream stream);
+
+/* silu_and_mul + dynamic per-token fp8 quantisation in one launch (MI355X-side fusion for the input of an fp8
+ * down_proj; ABI 4): out fp8 [num_tokens, d], scales float [num_tokens], input [num_tokens, 2 d].  The bits of
+ * mi355x_silu_and_mul followed by mi355x_dynamic_per_token_scaled_fp8_quant (no scale_ub).  Returns 1 (no error)
+ * when the fused form does not apply (d % 8 != 0, d > 16384, unaligned pointers): run the two ops. */
+int mi355x_silu_and_mul_per_token_quant(void* out, float* scales, const void* input, int num_tokens, int d,
+                                        int dtype, mi355x_stream stream);
 
 /* ------------------------------------------------------- int8 W8A8 (§8f-4) --
  * scaled_mm_int8: the int8 branch of cutlass_scaled_mm — out[M,N] (bf16/f16) =

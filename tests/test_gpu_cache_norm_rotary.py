@@ -591,3 +591,26 @@ def test_rotary_reshape_and_cache_is_bit_identical(dtype, T, KVH, D):
     assert_bit_exact(kc, kc_ref, "key cache")
     assert_bit_exact(vc, vc_ref, "value cache")
     assert_bit_exact(k, k_before, "key rows untouched")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d_", [8, 512, 3584, 14336, 16384])
+@pytest.mark.parametrize("tokens", [1, 64, 1100])
+def test_silu_and_mul_per_token_quant_equals_the_two_ops(dtype, d_, tokens):
+    """MI355X-side fusion for the input of an fp8 down_proj: the bytes and scales of silu_and_mul followed by
+    dynamic_per_token_scaled_fp8_quant, bit for bit; shapes it does not take report None."""
+    torch.manual_seed(2)
+    d = dev()
+    x = (torch.randn(tokens, 2 * d_) * 3).to(dtype).to(d)
+    x[0, :d_] = 0                       # an all-zero row: the minimum scale applies
+    got = ops().silu_and_mul_per_token_quant(x)
+    assert got is not None
+    mid = torch.empty(tokens, d_, dtype=dtype, device=d)
+    ops().silu_and_mul(mid, x)
+    want = torch.empty(tokens, d_, dtype=torch.float8_e4m3fn, device=d)
+    want_s = torch.empty(tokens, 1, dtype=torch.float32, device=d)
+    ops().dynamic_per_token_scaled_fp8_quant(want, mid, want_s, None)
+    assert torch.equal(got[1], want_s), "scales"
+    assert torch.equal(got[0].view(torch.uint8), want.view(torch.uint8)), "fp8 bytes"
+    assert ops().silu_and_mul_per_token_quant(torch.zeros(4, 2 * 20, dtype=dtype, device=d)) is None      # d % 8
+    assert ops().silu_and_mul_per_token_quant(torch.zeros(2, 2 * 16392, dtype=dtype, device=d)) is None   # d > 16384

@@ -66,6 +66,7 @@ PROTOTYPES = {
         _I, [_P, _P, _P, _P, _P, _I, _I, _L, _L, _L, _I, _I, _I, _I, _I, _P]),
     "mi355x_silu_and_mul": (_I, [_P, _P, _I, _I, _I, _P]),
     "mi355x_silu_and_mul_quant": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mi355x_silu_and_mul_per_token_quant": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mi355x_awq_to_gptq_4bit": (_I, [_P, _P, _I, _I, _P]),
     "mi355x_awq_dequantize": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "mi355x_awq_gemm": (_I, [_P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _L, _I, _P]),

@@ -520,6 +520,25 @@ def rotary_embedding(positions: torch.Tensor, query: torch.Tensor,
 
 
 # ------------------------------------------------------------------------ activation
+def silu_and_mul_per_token_quant(input: torch.Tensor):
+    """MI355X-side fusion: silu_and_mul(input) quantised per token to fp8 in the same launch -> (fp8 [T, d],
+    scales [T, 1]), bit-identical to silu_and_mul + dynamic_per_token_scaled_fp8_quant; None when the fused form
+    does not apply to these shapes."""
+    _dev(input)
+    if input.dim() != 2 or not input.is_contiguous() or input.dtype not in (torch.bfloat16, torch.float16):
+        return None
+    t, d2 = input.shape
+    d = d2 // 2
+    out = torch.empty((t, d), dtype=torch.float8_e4m3fn, device=input.device)
+    scales = torch.empty((t, 1), dtype=torch.float32, device=input.device)
+    rc = _abi.load().mi355x_silu_and_mul_per_token_quant(_ptr(out), _ptr(scales), _ptr(input), t, d, _dt(input),
+                                                         _stream())
+    if rc == 1:
+        return None
+    _abi.check(rc, "silu_and_mul_per_token_quant")
+    return out, scales
+
+
 def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
     _dev(out, input)
     if not (out.is_contiguous() and input.is_contiguous()):

@@ -63,6 +63,49 @@ __global__ void silu_and_mul_kernel(void* __restrict__ out_, const T* __restrict
   }
 }
 
+// silu_and_mul + dynamic per-token fp8 quantisation in one launch (the input of an fp8 down_proj): one workgroup
+// per token, the T-rounded products stay in registers between the row maximum and the quantisation.  The bits of
+// silu_and_mul followed by dynamic_per_token_scaled_fp8_quant (csrc/activation_kernels.cu:14-36, csrc/quantization/
+// fp8/common.cu:91-133: s = max(absmax / 448, 1 / (448 * 512)), q = sat(float(x) / s)); no reference op of its own.
+template <typename T, int MAXC>
+__global__ __launch_bounds__(256) void silu_mul_per_token_quant_kernel(
+    uint8_t* __restrict__ out, float* __restrict__ scales, const T* __restrict__ in, int d) {
+  __shared__ float red[16];
+  constexpr int V = 16 / sizeof(T);
+  const int64_t token = blockIdx.x;
+  const T* x = in + token * 2 * d;
+  const T* y = x + d;
+  Vec16<T> act[MAXC];
+  float m = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * 256 + threadIdx.x) * V;
+    if (i < d) {
+      const Vec16<T> xv = load16(x + i);
+      const Vec16<T> yv = load16(y + i);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        act[c].e[j] = mul_t<T>(silu_t<T>(xv.e[j]), yv.e[j]);
+        m = fmaxf(m, fabsf(to_f32(act[c].e[j])));
+      }
+    }
+  }
+  m = block_reduce<true>(m, red);
+  const float s = fmaxf(m / kFp8Max, kFp8MinScale);
+  if (threadIdx.x == 0) scales[token] = s;
+  uint8_t* o = out + token * d;
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    const int i = (c * 256 + threadIdx.x) * V;
+    if (i < d) {
+      uint8_t q[V];
+#pragma unroll
+      for (int j = 0; j < V; ++j) q[j] = f32_to_fp8_sat(to_f32(act[c].e[j]) / s);
+      *reinterpret_cast<uint2*>(o + i) = *reinterpret_cast<const uint2*>(q);
+    }
+  }
+}
+
 }  // namespace mi355x
 
 using namespace mi355x;
@@ -113,4 +156,29 @@ extern "C" int mi355x_silu_and_mul_quant(void* out, const void* input, const flo
   MI355X_REQUIRE(out && input && scale, MI355X_EINVAL, "silu_and_mul_quant: null pointer");
   return launch_silu<true>(out, input, scale, num_tokens, d, dtype,
                            static_cast<hipStream_t>(stream), "silu_and_mul_quant");
+}
+
+// returns 1 (no error) when the fused form does not apply (d % 8 != 0, d > 16384, unaligned): run the two ops
+extern "C" int mi355x_silu_and_mul_per_token_quant(void* out, float* scales, const void* input, int num_tokens,
+                                                   int d, int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && d > 0, MI355X_EINVAL, "silu_and_mul_per_token_quant: bad sizes");
+  MI355X_REQUIRE(dtype == MI355X_F16 || dtype == MI355X_BF16, MI355X_EUNSUPPORTED,
+                 "silu_and_mul_per_token_quant: input must be fp16 or bf16");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && scales && input, MI355X_EINVAL, "silu_and_mul_per_token_quant: null pointer");
+  if (d % 8 != 0 || d > 16384 || (reinterpret_cast<uintptr_t>(input) & 15) || (reinterpret_cast<uintptr_t>(out) & 7))
+    return 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return MI355X_DISPATCH_HALF(dtype, [&]() -> int {
+    const scalar_t* in = static_cast<const scalar_t*>(input);
+    uint8_t* o = static_cast<uint8_t*>(out);
+    const int chunks = (d / 8 + 255) / 256;
+    if (chunks <= 2)
+      hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 2>), dim3(num_tokens), dim3(256), 0, s, o, scales, in, d);
+    else if (chunks <= 4)
+      hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 4>), dim3(num_tokens), dim3(256), 0, s, o, scales, in, d);
+    else
+      hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 8>), dim3(num_tokens), dim3(256), 0, s, o, scales, in, d);
+    return check_launch("silu_and_mul_per_token_quant");
+  });
 }

@@ -432,6 +432,11 @@ class HotPathModel:
         act = L.gate_up.silu_mul(o)            # prefill-sized AWQ: fused into the GEMM epilogue
         if act is None:
             gu = L.gate_up(o)
+            if nq:                             # fp8: silu_and_mul + per-token quant of down_proj's input in one launch
+                qa = ops.silu_and_mul_per_token_quant(gu)
+                if qa is not None:
+                    act = QuantAct(qa[0], qa[1], gu.dtype)
+        if act is None:
             act = torch.empty(gu.shape[0], L.ffn, dtype=gu.dtype, device=gu.device)
             ops.silu_and_mul(act, gu)
         if fuse:
