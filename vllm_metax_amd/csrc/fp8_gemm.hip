@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
 //   * K split across workgroups (grid.y) through partial slabs [sk][m][n], summed in slab order by the finish
 //     kernel together with the scales / bias: deterministic, HIP-graph-replayable.
 //   fp8: one v_mfma_scale_f32_16x16x128_f8f6f4 per (row tile, column tile, k-step); int8: two 16x16x64.
-template <typename T, typename Op, int MT, int NT>
+template <typename T, typename Op, int MT, int NT, bool NTL = false>
 __global__ __launch_bounds__(256) void gemm8_decode_kernel(
     T* __restrict__ out, typename Op::elem_t* __restrict__ ws, const uint8_t* __restrict__ a,
     const uint8_t* __restrict__ b, const float* __restrict__ a_scales, int a_per_row,
@@ -399,8 +399,16 @@ __global__ __launch_bounds__(256) void gemm8_decode_kernel(
     const int kc = kk < nk ? kk : nk - 1;     // (clamped, not branched: beyond the range the last step is re-read)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      dst[t][0] = load_nt16(b_src[t] + kc * 128);
-      dst[t][1] = load_nt16(b_src[t] + kc * 128 + 64);
+      if constexpr (NTL) {
+        dst[t][0] = load_nt16(b_src[t] + kc * 128);
+        dst[t][1] = load_nt16(b_src[t] + kc * 128 + 64);
+      } else {
+        // default cache policy: the two halves of a column's 128-byte line are fetched by two instructions, and a
+        // non-temporal first half does not leave the line in L2 for the second (FETCH_SIZE: 2.1x the weight bytes
+        // with nt, profiles/r03_pmc_summary.txt)
+        dst[t][0] = *reinterpret_cast<const uint4*>(b_src[t] + kc * 128);
+        dst[t][1] = *reinterpret_cast<const uint4*>(b_src[t] + kc * 128 + 64);
+      }
     }
   };
 #pragma unroll
@@ -816,13 +824,17 @@ static bool plan_decode(int m, int n, int k, int64_t ws_elems, DecodePlan* p) {
 
 template <typename T, typename Op, int MT, int NT>
 static int launch_decode(const Fp8Args& g, int a_per_row, int b_per_col, const DecodePlan& p) {
-  auto kern = gemm8_decode_kernel<T, Op, MT, NT>;
+  static const bool nt_loads = [] { const char* e = getenv("MI355X_F8_NT"); return e && e[0] == '1'; }();
+  auto kern = nt_loads ? gemm8_decode_kernel<T, Op, MT, NT, true> : gemm8_decode_kernel<T, Op, MT, NT, false>;
   const size_t smem = (size_t)MT * p.steps * 2048;
   static PerDeviceOnce once;   // one per instantiation
   int dev;
   if (once.need(&dev)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_decode_kernel<T, Op, MT, NT, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_decode_kernel<T, Op, MT, NT, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) {
       set_error("scaled_mm(decode): cannot reserve 128 KiB of LDS: %s", hipGetErrorString(e));
       return MI355X_EUNSUPPORTED;

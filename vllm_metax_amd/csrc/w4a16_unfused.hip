@@ -21,6 +21,8 @@
 // chunk l%4 -> ds_write_b128, 8-lane groups) bank-conflict free (derivation in DESIGN.md §3).
 // Column tiles are interleaved inside a 64-column group exactly as in the fused kernel
 // (tile t owns columns 64q + 4c + t), so a lane's 4 accumulators are 4 consecutive columns.
+#include <cstdlib>
+
 #include "w4a16.cuh"
 
 namespace mi355x {
@@ -326,6 +328,12 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   }
 }
 
+// (Round 3 built the obvious alternative — 4 waves, one per SIMD, a 128 x 128 quadrant each: a third fewer LDS bytes
+//  per flop, 256 accumulators per lane, the next stage's fragments read into a second register set — and measured it
+//  against this kernel on one box (scripts/ab_r03.sh): 1322-1332 vs 1493-1495 TFLOP/s on random operands, 1485 vs
+//  1990 on zeros.  Without a SIMD partner the 16 fragment reads and 8 copy issues of a stage are not hidden; placed
+//  between the MFMA groups they pushed hipcc over the 512-register file (B fragments in AGPRs, 40 scratch
+//  accesses).  Removed from the source; the two-waves-per-SIMD ping-pong stays.)
 static inline int64_t unfused_scratch_bytes(int m, int n, int k) {
   const int64_t m_pad = ((int64_t)m + 15) / 16 * 16;
   return ((int64_t)n + m_pad) * k * 2;
