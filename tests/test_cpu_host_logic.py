@@ -12,7 +12,8 @@ from vllm_metax_amd.platform import Mi355xPlatform
 
 def test_entry_points():
     assert vllm_metax_amd.register() == "vllm_metax_amd.platform.Mi355xPlatform"
-    assert vllm_metax_amd.register_patch() is None and vllm_metax_amd.register_model() is None
+    # register_patch() returns the list of upstream classes it patched: none without vLLM installed
+    assert vllm_metax_amd.register_patch() == [] and vllm_metax_amd.register_model() is None
 
 
 def test_split_decodes_and_prefills():
