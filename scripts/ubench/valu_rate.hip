@@ -44,24 +44,49 @@ __global__ void k(uint64_t* out, uint32_t seed, int iters) {
                        asm volatile("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(f1) : "v"(b));
                        asm volatile("v_cvt_f32_u32_e32 %0, %1" : "=v"(f2) : "v"(c));
                        asm volatile("v_cvt_f32_i32_e32 %0, %1" : "=v"(f3) : "v"(d));) }
+    // round 3: fp8 -> f32 pair converts (a byte 0x0q read as e4m3 is q * 2^-9: the int4 nibble as a denormal-continuous fp8)
+    if (WHICH == 8) { REP16(asm volatile("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_0" : "=v"(p0) : "v"(a));
+                       asm volatile("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_1" : "=v"(p1) : "v"(b));
+                       asm volatile("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_0" : "=v"(p2) : "v"(c));
+                       asm volatile("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_1" : "=v"(p3) : "v"(d));) }
+    if (WHICH == 9) { REP16(asm volatile("v_cvt_scalef32_pk_f32_fp8 %0, %1, %2" : "=v"(p0) : "v"(a), "v"(g0));
+                       asm volatile("v_cvt_scalef32_pk_f32_fp8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(p1) : "v"(b), "v"(g0));
+                       asm volatile("v_cvt_scalef32_pk_f32_fp8 %0, %1, %2" : "=v"(p2) : "v"(c), "v"(g0));
+                       asm volatile("v_cvt_scalef32_pk_f32_fp8 %0, %1, %2 op_sel:[1,0,0]" : "=v"(p3) : "v"(d), "v"(g0));) }
+    if (WHICH == 10) { REP16(asm volatile("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2" : "=v"(a) : "v"(b), "v"(g0));
+                       asm volatile("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2 op_sel:[1,0,0,0]" : "=v"(b) : "v"(c), "v"(g0));
+                       asm volatile("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2" : "=v"(c) : "v"(d), "v"(g0));
+                       asm volatile("v_cvt_scalef32_pk_bf16_fp8 %0, %1, %2 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(g0));) }
   }
   uint64_t t1 = __builtin_readcyclecounter();
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
-  if (f0 + f1 + f2 + f3 + p0.x + p1.y == 12345.f && a + b + c + d == 77) out[1] = 1;
+  if (f0 + f1 + f2 + f3 + p0.x + p1.y + p2.x + p3.y == 12345.f && a + b + c + d == 77) out[1] = 1;
+}
+__global__ void nib(float* out) {
+  // out[q] = v_cvt_pk_f32_fp8(0x0q) for q = 0..15 (expected q * 2^-9 with OCP e4m3)
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  uint32_t w = threadIdx.x & 15;
+  f2_t r;
+  asm volatile("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_0" : "=v"(r) : "v"(w));
+  if (threadIdx.x < 16) out[threadIdx.x] = r.x;
 }
 int main() {
+  { float* o; hipMalloc(&o, 64); hipLaunchKernelGGL(nib, dim3(1), dim3(64), 0, 0, o); float h[16];
+    hipMemcpy(h, o, 64, hipMemcpyDeviceToHost); printf("nibble as e4m3 * 512:");
+    for (int i = 0; i < 16; ++i) printf(" %g", h[i] * 512.f); printf("\n"); }
   uint64_t* d; hipMalloc(&d, 16);
-  const char* names[] = {"v_cvt_f32_ubyteN", "v_cvt_pk_bf16_f32", "v_pk_fma_f32", "v_fma_f32", "and/shift/bfe", "v_perm_b32", "v_and_or / v_lshl_or", "v_cvt_f32_u32 (sdwa/plain)"};
+  const char* names[] = {"v_cvt_f32_ubyteN", "v_cvt_pk_bf16_f32", "v_pk_fma_f32", "v_fma_f32", "and/shift/bfe", "v_perm_b32", "v_and_or / v_lshl_or", "v_cvt_f32_u32 (sdwa/plain)", "v_cvt_pk_f32_fp8 (sdwa)",
+                         "v_cvt_scalef32_pk_f32_fp8", "v_cvt_scalef32_pk_bf16_fp8"};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int waves = 1; waves <= 4; waves *= 2) {
-    for (int w = 0; w < 8; ++w) {
+    for (int w = 0; w < 11; ++w) {
       const int iters = 20000;
       dim3 block(256 * waves), grid(256);  // one block per CU, `waves` waves per SIMD
       #define L(W) hipLaunchKernelGGL(k<W>, grid, block, 0, 0, d, 1u, iters)
       float ms = 0;
       for (int r = 0; r < 2; ++r) {
         hipEventRecord(e0);
-        if (w == 0) L(0); if (w == 1) L(1); if (w == 2) L(2); if (w == 3) L(3); if (w == 4) L(4); if (w == 5) L(5); if (w == 6) L(6); if (w == 7) L(7);
+        if (w == 0) L(0); if (w == 1) L(1); if (w == 2) L(2); if (w == 3) L(3); if (w == 4) L(4); if (w == 5) L(5); if (w == 6) L(6); if (w == 7) L(7); if (w == 8) L(8); if (w == 9) L(9); if (w == 10) L(10);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
       }
       // SIMD-cycles per wave-instruction at 2.4 GHz: time * 2.4e9 / (instructions per SIMD)
