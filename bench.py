@@ -229,7 +229,7 @@ def instrument(model, timer: EventTimer):
          cost_prefill(None, q, kc, vc, kvh, scale, bt, sl, cu, max_q, bs), record_as="paged_prefill_attention")
 
     def cost_decode_fused(out, es, ml, tmp, qkv, slabs, sk, positions, cos_sin, slots, kc, vc, nh, kvh, scale, bt,
-                          sl, bs, max_len, partitioned):
+                          sl, bs, max_len, partitioned, *a, **k):
         # the attention bytes (as paged_attention_v1 / _v2) + the qkv row / slabs of the folded qkv_rope_cache
         S, D = qkv.shape[0], kc.shape[2] * kc.shape[4]
         mean_len = model.mean_decode_len_for_cost

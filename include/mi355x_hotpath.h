@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 4   /* 4: + paged_prefill_attention_alibi, silu_and_mul_per_token_quant (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
+#define MI355X_ABI_VERSION 5   /* 5: + paged_attention_v2_ps (additive); 4: + paged_prefill_attention_alibi, silu_and_mul_per_token_quant (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
                                 * 2 was BREAKING (kv_cache_dtype / k_scale / v_scale inserted before `stream` in reshape_and_cache*,
                                 * paged_attention_v1/_v2, paged_prefill_attention): a binding must refuse a library whose
                                 * mi355x_abi_version() differs from the version it was written for (vllm_metax_amd/_abi.py does) */
@@ -159,6 +159,22 @@ int mi355x_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
                               int64_t q_stride, int64_t kv_block_stride,
                               int64_t kv_head_stride, int dtype, int kv_cache_dtype,
                               const float* k_scale, const float* v_scale, mi355x_stream stream);
+/* The same with the partition size chosen by the caller (a positive multiple of the block size and of 16;
+ * exp_sums / max_logits / tmp_out sized for P = ceil(max_seq_len / partition_size)).  The reference fixes 512
+ * (paged_attention_v2.cu:45); with few (sequence, kv head) pairs — one TP = 8 rank of a 70B model at batch 64
+ * has 64 — 512-token partitions leave most CUs without a workgroup, so the host side
+ * (attention/backend.py::decode_partition_size) splits finer.  mi355x_paged_attention_v2 == partition_size 512. */
+int mi355x_paged_attention_v2_ps(void* out, float* exp_sums, float* max_logits,
+                                 void* tmp_out, const void* query, const void* key_cache,
+                                 const void* value_cache, int num_seqs, int num_heads,
+                                 int num_kv_heads, int head_size, int block_size,
+                                 float scale, const int* block_tables,
+                                 const int* seq_lens, int max_num_blocks_per_seq,
+                                 int max_seq_len, const float* alibi_slopes,
+                                 int64_t q_stride, int64_t kv_block_stride,
+                                 int64_t kv_head_stride, int dtype, int kv_cache_dtype,
+                                 const float* k_scale, const float* v_scale, int partition_size,
+                                 mi355x_stream stream);
 
 /* Paged prefill / chunked prefill (varlen, causal bottom-right aligned, GQA) over
  * the SAME x-split paged cache (the new tokens were already written by

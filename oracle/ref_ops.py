@@ -160,11 +160,14 @@ def paged_attention_v1(query, key_cache, value_cache, num_kv_heads, scale, block
 
 
 def paged_attention_v2(query, key_cache, value_cache, num_kv_heads, scale, block_tables,
-                       seq_lens, max_seq_len, alibi_slopes=None):
+                       seq_lens, max_seq_len, alibi_slopes=None, partition_size=None):
     """attention_kernels.cuh:519-551 (partitions of 512 tokens, per-partition max/sum
     :338-346, tmp_out in scalar_t :481) + reduce :553-658.  Returns (out, exp_sums,
-    max_logits, tmp_out); entries of partitions past seq_len are left at zero."""
+    max_logits, tmp_out); entries of partitions past seq_len are left at zero.
+    `partition_size`: the same arithmetic with another partition length (the reference fixes 512,
+    paged_attention_v2.cu:45; the MI355X launcher may split finer, mi355x_paged_attention_v2_ps)."""
     S, H, D = query.shape
+    PARTITION_SIZE = partition_size or globals()["PARTITION_SIZE"]
     P = max((max_seq_len + PARTITION_SIZE - 1) // PARTITION_SIZE, 1)
     dt = query.dtype
     out = torch.zeros(S, H, D, dtype=dt)

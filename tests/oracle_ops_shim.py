@@ -66,9 +66,9 @@ def paged_attention_v1(out, q, kc, vc, kvh, scale, bt, sl, bs, max_len, alibi, k
 
 
 def paged_attention_v2(out, es, ml, tmp, q, kc, vc, kvh, scale, bt, sl, bs, max_len, alibi,
-                       kv_cache_dtype="auto", k_scale=None, v_scale=None, *a):
+                       kv_cache_dtype="auto", k_scale=None, v_scale=None, *a, partition_size=PARTITION_SIZE):
     kc, vc = _caches(kc, vc, kv_cache_dtype, k_scale, v_scale, q.dtype)
-    out.copy_(R.paged_attention_v2(q, kc, vc, kvh, scale, bt, sl, max_len, alibi)[0])
+    out.copy_(R.paged_attention_v2(q, kc, vc, kvh, scale, bt, sl, max_len, alibi, partition_size)[0])
 
 
 def paged_attention_v1_max_seq_len(num_seqs, num_heads, num_kv_heads, head_size, block_size, dtype):

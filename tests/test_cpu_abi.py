@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol(built):
         assert hasattr(lib, sym), f"{sym} declared in the header but not exported"
     # and the ctypes prototype table covers exactly the header
     assert sorted(built.PROTOTYPES) == header_symbols()
-    assert lib.mi355x_abi_version() == built.ABI_VERSION == 4
+    assert lib.mi355x_abi_version() == built.ABI_VERSION == 5
 
 
 def test_argument_errors_surface_without_a_gpu(built):

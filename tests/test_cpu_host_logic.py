@@ -144,9 +144,42 @@ def test_decode_workspace_views_and_fixed_geometry():
     slots = torch.zeros(3, dtype=torch.int64)
     md = B.build_metadata(qsl, qsl.tolist(), sl, sl.tolist(), bt, slots, 3, 1, 700, 4, 16, torch.float32, ws,
                           num_kv_heads=4, block_size=16, fixed_decode_len=2000)
-    assert md.max_decode_seq_len == 2000 and md.exp_sums.shape == (3, 4, 4)
+    # 3 sequences x 4 kv heads are 12 workgroups per partition: the split goes down to the 128-token floor
+    assert md.max_decode_seq_len == 2000 and md.partition_size == 128 and md.exp_sums.shape == (3, 4, 16)
     assert md.exp_sums.data_ptr() == ws.exp_sums.data_ptr()
-    assert md.use_v1 is False                              # 12 (seq, head) pairs, 4 partitions -> v2
+    assert md.use_v1 is False                              # 12 (seq, head) pairs, several partitions -> v2
     md2 = B.build_metadata(qsl, qsl.tolist(), sl, sl.tolist(), bt, slots, 3, 1, 700, 4, 16, torch.float32, ws,
                            num_kv_heads=4, block_size=16)
-    assert md2.max_decode_seq_len == 700 and md2.exp_sums.shape == (3, 4, 2)
+    assert md2.max_decode_seq_len == 700 and md2.exp_sums.shape == (3, 4, 6)
+    md3 = B.build_metadata(qsl, qsl.tolist(), sl, sl.tolist(), bt, slots, 3, 1, 700, 4, 16, torch.float32, ws)
+    assert md3.partition_size == 512 and md3.exp_sums.shape == (3, 4, 2)   # kv head count unknown: the reference's 512
+
+
+def test_decode_partition_size_and_workspace():
+    """Host rule behind mi355x_paged_attention_v2_ps: the reference's 512-token partitions unless they leave CUs
+    without a workgroup; never below 128 tokens; a multiple of the block size and of 16."""
+    # Llama-3-8B, batch 64: 64 x 8 kv heads already fill the chip
+    assert B.decode_partition_size(64, 32, 8, 1152, 16) == 512
+    # one TP = 8 rank of Llama-3-70B, batch 64 (8 q / 1 kv head, one workgroup per kv head): 4 partitions of 288
+    assert B.decode_heads_per_workgroup(8, 1) == 8 and B.decode_heads_per_workgroup(32, 8) == 4
+    assert B.decode_partition_size(64, 8, 1, 1152, 16) == 288
+    assert B.decode_partition_size(8, 8, 1, 1152, 16) == 128          # small batch: the floor
+    assert B.decode_partition_size(64, 8, 1, 100, 16) == 512          # short contexts: one partition anyway
+    assert B.decode_partition_size(1, 8, 1, 131072, 32) == 512        # 256 partitions of 512 are enough
+    for n in (1, 3, 64, 200):
+        for L in (129, 1000, 5000, 40000):
+            for bs in (8, 16, 32):
+                ps = B.decode_partition_size(n, 8, 1, L, bs)
+                assert 128 <= ps <= 512 and ps % bs == 0 and ps % 16 == 0
+    ws = B.DecodeWorkspace(64, 8, 128, 4096, torch.bfloat16, "cpu")
+    ps = B.decode_partition_size(64, 8, 1, 1152, 16)
+    es, ml, to = ws.views(64, -(-1152 // ps))
+    assert es.shape == (64, 8, 4) and to.shape == (64, 8, 4, 128) and es.is_contiguous() and to.is_contiguous()
+    ps1 = B.decode_partition_size(1, 8, 1, 4096, 16)
+    es, ml, to = ws.views(1, -(-4096 // ps1))                         # one sequence, 32 partitions of 128
+    assert es.shape == (1, 8, 32)
+    md = B.build_metadata(torch.arange(65, dtype=torch.int32), list(range(65)), torch.full((64,), 1100, dtype=torch.int32),
+                          [1100] * 64, torch.zeros(64, 72, dtype=torch.int32), torch.arange(64), 64, 1, 1100,
+                          num_heads=8, head_size=128, dtype=torch.bfloat16, workspace=ws, num_kv_heads=1,
+                          fixed_decode_len=1152)
+    assert md.partition_size == 288 and md.exp_sums.shape == (64, 8, 4) and md.use_v1 is False

@@ -276,7 +276,7 @@ def test_decode_attention_v1_v2_boundary(dtype, max_len, expect_v1):
 
 def test_paged_attention_tp8_per_rank_heads():
     """Per-rank head shape of Llama-3-70B / Qwen2-72B at TP=8: 8 query heads, ONE kv head
-    (two head tiles of 4 per workgroup column), contexts across partition boundaries."""
+    (one workgroup serves all 8 since round 3), contexts across partition boundaries."""
     seq_lens = [1, 16, 511, 513, 1151, 2049]
     for dtype in (torch.bfloat16, torch.float16):
         args = _setup(len(seq_lens), 8, 1, 128, 16, dtype, seq_lens, seed=21)
@@ -288,14 +288,53 @@ def test_paged_attention_tp8_per_rank_heads():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("heads", [(8, 1), (32, 8), (10, 2), (16, 1)])
+@pytest.mark.parametrize("ps", [128, 208, 288, 512])
+def test_paged_attention_v2_partition_sizes(dtype, heads, ps):
+    """mi355x_paged_attention_v2_ps: the v2 arithmetic (attention_kernels.cuh:519-658) with the caller's partition
+    size against the oracle run with the same partition size — output and the per-partition statistics; head
+    geometries: one TP = 8 rank (8 q / 1 kv: one 8-head workgroup), Llama-3-8B, 5 q per kv (8-head workgroup with
+    absent heads), 16 q per kv (two 8-head tiles)."""
+    H, KVH = heads
+    seq_lens = [1, 16, ps - 1, ps, ps + 1, 1151, 2 * ps + 17]
+    args = _setup(len(seq_lens), H, KVH, 128, 16, dtype, seq_lens, seed=5 + ps)
+    q, kc, vc, bt, sl, slopes, scale, max_len = args
+    ref, es_r, ml_r, tmp_r = R.paged_attention_v2(q, kc, vc, KVH, scale, bt, sl, max_len, slopes, ps)
+    d = dev()
+    S, _, D = q.shape
+    P = (max_len + ps - 1) // ps
+    out = torch.full_like(q, float("nan"), device=d)
+    tmp = torch.empty(S, H, P, D, dtype=dtype, device=d)
+    es = torch.empty(S, H, P, dtype=torch.float32, device=d)
+    ml = torch.empty_like(es)
+    ops().paged_attention_v2(out, es, ml, tmp, q.to(d), kc.to(d), vc.to(d), KVH, scale, bt.to(d), sl.to(d), 16,
+                             max_len, None, "auto", partition_size=ps)
+    torch.cuda.synchronize()
+    assert_close_rel(out, ref, 1e-3, f"v2 ps={ps}", abs_floor=_tol(ref))
+    for s in range(S):
+        np_ = (seq_lens[s] + ps - 1) // ps
+        assert_close_rel(ml[s, :, :np_], ml_r[s, :, :np_], 1e-5, "max_logits", abs_floor=1e-5)
+        assert_close_rel(es[s, :, :np_], es_r[s, :, :np_], 1e-4, "exp_sums")
+    with pytest.raises(RuntimeError, match="partition"):
+        ops().paged_attention_v2(out, es, ml, tmp, q.to(d), kc.to(d), vc.to(d), KVH, scale, bt.to(d), sl.to(d), 16,
+                                 max_len, None, "auto", partition_size=ps // 2)   # workspaces too small
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("sk", [0, 3])
 @pytest.mark.parametrize("partitioned", [False, True])
-def test_fused_qkv_attention_is_bit_identical(dtype, sk, partitioned):
+@pytest.mark.parametrize("geom", [(8, 2, 512), (8, 1, 512), (8, 1, 128), (8, 2, 272)])
+def test_fused_qkv_attention_is_bit_identical(dtype, sk, partitioned, geom):
     """mi355x_paged_attention_fused_qkv == qkv_rope_cache followed by paged_attention_v1 / _v2, bit for bit:
     attention output and both caches (ragged lengths incl. a token that opens a new block, a sequence of one
-    token, a context that spans several 512-token partitions)."""
+    token, a context that spans several partitions).  Geometries: 4 query heads per kv head (Llama-3-8B) and
+    8 per kv head = ONE workgroup for all heads of a TP = 8 rank of Llama-3-70B / Qwen2-72B (round 3), with the
+    reference's 512-token partitions and with the finer ones decode_partition_size picks."""
     from vllm_metax_amd import _custom_ops as ops
-    H, KVH, D, BS = 8, 2, 128, 16
+    H, KVH, PS = geom
+    D, BS = 128, 16
+    if not partitioned and PS != 512:
+        pytest.skip("partition size only matters for the partitioned launch")
     lens = [1, 16, 17, 33, 512, 513, 1100, 640]
     n = len(lens)
     g = torch.Generator().manual_seed(11 + sk)
@@ -314,7 +353,7 @@ def test_fused_qkv_attention_is_bit_identical(dtype, sk, partitioned):
     slabs = (torch.randn(max(sk, 1), n, width, generator=g) * 0.3).to(d)
     cos_sin = torch.randn(2048, D, generator=g).to(dtype).to(d)
     scale = D ** -0.5
-    P = (max_len + ops.PARTITION_SIZE - 1) // ops.PARTITION_SIZE
+    P = (max_len + PS - 1) // PS
     es = torch.empty(n, H, P, dtype=torch.float32, device=d)
     ml = torch.empty_like(es)
     tmp = torch.empty(n, H, P, D, dtype=dtype, device=d)
@@ -325,7 +364,8 @@ def test_fused_qkv_attention_is_bit_identical(dtype, sk, partitioned):
         out = torch.empty(n, H, D, dtype=dtype, device=d)
         q3 = q2[:, :H * D].view(n, H, D)
         if partitioned:
-            ops.paged_attention_v2(out, es, ml, tmp, q3, k2, v2, KVH, scale, bt, sl, BS, max_len, None)
+            ops.paged_attention_v2(out, es, ml, tmp, q3, k2, v2, KVH, scale, bt, sl, BS, max_len, None,
+                                   partition_size=PS)
         else:
             ops.paged_attention_v1(out, q3, k2, v2, KVH, scale, bt, sl, BS, max_len, None)
         return out, k2, v2
@@ -334,17 +374,19 @@ def test_fused_qkv_attention_is_bit_identical(dtype, sk, partitioned):
     k3, v3 = kc.clone(), vc.clone()
     out = torch.empty(n, H, D, dtype=dtype, device=d)
     ok = ops.paged_attention_fused_qkv(out, es, ml, tmp, qkv.clone(), slabs, sk, pos, cos_sin, slots, k3, v3,
-                                       H, KVH, scale, bt, sl, BS, max_len, partitioned)
+                                       H, KVH, scale, bt, sl, BS, max_len, partitioned, PS)
     assert ok
     assert_bit_exact(k3, ref_k, "key cache")
     assert_bit_exact(v3, ref_v, "value cache")
     assert_bit_exact(out, ref_out, "attention output")
-    # not applicable (8 query heads per kv head -> two workgroups per kv head): reports False, launches nothing
+    # not applicable (10 query heads per kv head -> two workgroups per kv head): reports False, launches nothing
     k4 = kc.clone()
-    out10 = torch.empty(n, H + 2, D, dtype=dtype, device=d)
-    es10 = torch.empty(n, H + 2, P, dtype=torch.float32, device=d)
-    tmp10 = torch.empty(n, H + 2, P, D, dtype=dtype, device=d)
-    assert not ops.paged_attention_fused_qkv(out10, es10, es10.clone(), tmp10, qkv.clone(), slabs, sk, pos, cos_sin,
-                                             slots, k4[:, :1], v3[:, :1], H + 2, 1, scale, bt, sl, BS, max_len,
-                                             partitioned)
+    out10 = torch.empty(n, 10, D, dtype=dtype, device=d)
+    es10 = torch.empty(n, 10, P, dtype=torch.float32, device=d)
+    tmp10 = torch.empty(n, 10, P, D, dtype=dtype, device=d)
+    qkv12 = torch.zeros(n, 12 * D, dtype=dtype, device=d)
+    slabs12 = torch.zeros(max(sk, 1), n, 12 * D, device=d)
+    assert not ops.paged_attention_fused_qkv(out10, es10, es10.clone(), tmp10, qkv12, slabs12, sk, pos, cos_sin,
+                                             slots, k4[:, :1], v3[:, :1], 10, 1, scale, bt, sl, BS, max_len,
+                                             partitioned, PS)
     assert_bit_exact(k4, kc, "untouched")

@@ -16,7 +16,7 @@ LIB_PATH = PKG_DIR / "libmi355x_hotpath.so"
 
 F16, BF16, F32 = 0, 1, 2
 KV_AUTO, KV_FP8_E4M3 = 0, 1          # mi355x_kv_cache_dtype
-ABI_VERSION = 4                      # the MI355X_ABI_VERSION the PROTOTYPES below were written for
+ABI_VERSION = 5                      # the MI355X_ABI_VERSION the PROTOTYPES below were written for
 
 _P = c_void_p
 _I = c_int
@@ -43,6 +43,9 @@ PROTOTYPES = {
     "mi355x_paged_attention_v2": (
         _I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _L, _L, _L,
              _I, _I, _P, _P, _P]),
+    "mi355x_paged_attention_v2_ps": (
+        _I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _P, _L, _L, _L,
+             _I, _I, _P, _P, _I, _P]),
     "mi355x_paged_prefill_attention": (
         _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P, _I, _I, _L, _L, _L, _L, _I, _I, _P,
              _P, _I, _F, _P]),

@@ -241,19 +241,26 @@ def paged_attention_v2(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: to
                        v_scale: Optional[torch.Tensor] = None, tp_rank: int = 0,
                        blocksparse_local_blocks: int = 0, blocksparse_vert_stride: int = 0,
                        blocksparse_block_size: int = 64,
-                       blocksparse_head_sliding_step: int = 0) -> None:
+                       blocksparse_head_sliding_step: int = 0,
+                       partition_size: int = PARTITION_SIZE) -> None:
+    """`partition_size` (beyond the reference's signature, default = its fixed 512): tokens per split-KV partition;
+    exp_sums / max_logits / tmp_out must hold ceil(max_seq_len / partition_size) partitions."""
     kvd, ks, vs = _kv_dtype(kv_cache_dtype, key_cache, k_scale, v_scale)
     _check_blocksparse(blocksparse_vert_stride)
     _dev(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, block_tables,
          seq_lens, alibi_slopes)
     if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
         raise RuntimeError("block_tables and seq_lens must be int32")
-    rc = _abi.load().mi355x_paged_attention_v2(
+    parts = (max_seq_len + partition_size - 1) // max(partition_size, 1)
+    if partition_size <= 0 or exp_sums.numel() < query.size(0) * query.size(1) * parts \
+            or tmp_out.numel() < query.size(0) * query.size(1) * parts * query.size(2):
+        raise RuntimeError(f"paged_attention_v2: workspaces too small for {parts} partitions of {partition_size}")
+    rc = _abi.load().mi355x_paged_attention_v2_ps(
         _ptr(out), _ptr(exp_sums), _ptr(max_logits), _ptr(tmp_out), _ptr(query),
         _ptr(key_cache), _ptr(value_cache), query.size(0), query.size(1), num_kv_heads,
         query.size(2), block_size, float(scale), _ptr(block_tables), _ptr(seq_lens),
         block_tables.size(1), max_seq_len, _ptr(alibi_slopes), query.stride(0),
-        key_cache.stride(0), key_cache.stride(1), _dt(query), kvd, ks, vs, _stream())
+        key_cache.stride(0), key_cache.stride(1), _dt(query), kvd, ks, vs, int(partition_size), _stream())
     _abi.check(rc, "paged_attention_v2")
 
 
@@ -822,7 +829,7 @@ def paged_attention_fused_qkv(out: torch.Tensor, exp_sums: Optional[torch.Tensor
                               slot_mapping: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
                               num_heads: int, num_kv_heads: int, scale: float, block_tables: torch.Tensor,
                               seq_lens: torch.Tensor, block_size: int, max_seq_len: int,
-                              partitioned: bool) -> bool:
+                              partitioned: bool, partition_size: int = PARTITION_SIZE) -> bool:
     """MI355X-side decode fusion: qkv_rope_cache folded into the paged-attention launch that follows it
     (include/mi355x_hotpath.h).  Returns False when the fused form does not apply to these shapes — the
     caller then runs qkv_rope_cache + paged_attention_v1 / _v2.  `out` [n, H, D]; the qkv buffer is not updated."""
@@ -852,7 +859,7 @@ def paged_attention_fused_qkv(out: torch.Tensor, exp_sums: Optional[torch.Tensor
         int(sk), _ptr(positions), _ptr(cos_sin_cache), _ptr(slot_mapping), _ptr(key_cache), _ptr(value_cache),
         n, num_heads, num_kv_heads, head_size, block_size, key_cache.size(4), float(scale), _ptr(block_tables),
         _ptr(seq_lens), block_tables.stride(0), max_seq_len, key_cache.stride(0), key_cache.stride(1),
-        PARTITION_SIZE if partitioned else 0, _dt(qkv), _stream())
+        int(partition_size) if partitioned else 0, _dt(qkv), _stream())
     if rc == 1:
         return False
     _abi.check(rc, "paged_attention_fused_qkv")

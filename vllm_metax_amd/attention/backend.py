@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import dataclasses
 import functools
+import math
 from typing import Optional, Tuple
 
 import torch
@@ -55,11 +56,44 @@ class Mi355xPagedMetadata:
     tmp_out: Optional[torch.Tensor] = None
     # v1 / v2 decided once per step from the launcher's own LDS budget (None: decide per call)
     use_v1: Optional[bool] = None
+    # tokens per split-KV partition of the v2 launch (decode_partition_size)
+    partition_size: int = PARTITION_SIZE
+
+
+MIN_PARTITION_SIZE = 128     # finest split decode_partition_size chooses
+TARGET_DECODE_WGS = 256      # one workgroup per CU
+
+
+def decode_heads_per_workgroup(num_heads: int, num_kv_heads: int) -> int:
+    """Query heads of one kv head that one decode workgroup serves (csrc/paged_attention.hip::pa_plan)."""
+    q_per_kv = num_heads // num_kv_heads
+    return 8 if q_per_kv >= 5 else (4 if q_per_kv >= 3 else q_per_kv)
+
+
+def decode_partition_size(num_seqs: int, num_heads: int, num_kv_heads: int, max_seq_len: int,
+                          block_size: int) -> int:
+    """Tokens per split-KV partition for paged_attention_v2.  The reference's launcher fixes 512
+    (csrc/attention/paged_attention_v2.cu:45) and its grid is (heads, seqs, partitions); here one workgroup
+    serves all (up to 8) query heads of a kv head, so a TP = 8 rank of a 70B model at batch 64 (8 q / 1 kv
+    head) has 64 x ceil(L / 512) workgroups for 256 CUs.  When 512-token partitions give fewer than one
+    workgroup per CU the partitions are cut finer — never below 128 tokens — so that about one workgroup per CU
+    streams the cache (measured: profiles/r03 notes).  A multiple of the block size and of 16."""
+    gt = decode_heads_per_workgroup(num_heads, num_kv_heads)
+    base = num_seqs * num_kv_heads * (-(-(num_heads // num_kv_heads) // gt))
+    if base <= 0 or max_seq_len <= MIN_PARTITION_SIZE:
+        return PARTITION_SIZE
+    if base * (-(-max_seq_len // PARTITION_SIZE)) >= TARGET_DECODE_WGS:
+        return PARTITION_SIZE
+    want = -(-TARGET_DECODE_WGS // base)                  # partitions per sequence
+    unit = block_size * 16 // math.gcd(block_size, 16)
+    ps = -(-max_seq_len // want)
+    ps = -(-ps // unit) * unit
+    return max(MIN_PARTITION_SIZE, min(PARTITION_SIZE, ps))
 
 
 class DecodeWorkspace:
     """Split-KV buffers of paged_attention_v2, allocated ONCE for (max_num_seqs, ceil(max_model_len /
-    512)) and handed out as views.  build() used to torch.empty() them per step: under a full HIP-graph
+    512)) — plus room for the finer partitions decode_partition_size picks for small batches — and handed out as views.  build() used to torch.empty() them per step: under a full HIP-graph
     capture the graph keeps the capture-time addresses, which the allocator may have reused by replay
     time.  Invariant: every pointer a captured decode launch sees belongs to a buffer that
     outlives the graph."""
@@ -69,16 +103,19 @@ class DecodeWorkspace:
         self.max_num_seqs = max_num_seqs
         self.max_parts = max((max_model_len + PARTITION_SIZE - 1) // PARTITION_SIZE, 1)
         self.max_model_len = max_model_len
-        self.exp_sums = torch.empty(max_num_seqs, num_heads, self.max_parts, dtype=torch.float32, device=device)
+        # (sequence, partition) pairs: 512-token partitions for a full batch; a finer split is only chosen while
+        # seqs * partitions stays below ~TARGET_DECODE_WGS + seqs (decode_partition_size)
+        self.max_pairs = max_num_seqs * (self.max_parts + 1) + TARGET_DECODE_WGS
+        self.exp_sums = torch.empty(self.max_pairs, num_heads, dtype=torch.float32, device=device)
         self.max_logits = torch.empty_like(self.exp_sums)
-        self.tmp_out = torch.empty(max_num_seqs, num_heads, self.max_parts, head_size, dtype=dtype, device=device)
+        self.tmp_out = torch.empty(self.max_pairs, num_heads, head_size, dtype=dtype, device=device)
 
     def views(self, num_seqs: int, parts: int):
-        if num_seqs > self.max_num_seqs or parts > self.max_parts:
+        if num_seqs > self.max_num_seqs or num_seqs * parts > self.max_pairs:
             raise RuntimeError(f"decode workspace too small: {num_seqs} seqs x {parts} partitions "
-                               f"(sized for {self.max_num_seqs} x {self.max_parts})")
+                               f"(sized for {self.max_pairs} (sequence, partition) pairs)")
         n = num_seqs
-        h, d = self.exp_sums.shape[1], self.tmp_out.shape[-1]
+        h, d = self.exp_sums.shape[-1], self.tmp_out.shape[-1]
         # contiguous [n, h, parts(, d)] views of the flat storage: the kernels index with `parts` as the
         # partition stride, so the views must be dense in the shape they are launched with
         es = self.exp_sums.view(-1)[:n * h * parts].view(n, h, parts)
@@ -128,7 +165,9 @@ def build_metadata(query_start_loc: torch.Tensor, query_start_loc_cpu, seq_lens:
         # value instead of the batch's current maximum, so a replay with longer sequences stays inside
         # what was captured (the kernels read the true lengths from seq_lens on the device)
         md.max_decode_seq_len = fixed_decode_len if fixed_decode_len else (max(sl_cpu[:nd]) if sl_cpu else 0)
-        parts = max((md.max_decode_seq_len + PARTITION_SIZE - 1) // PARTITION_SIZE, 1)
+        if num_kv_heads is not None:
+            md.partition_size = decode_partition_size(nd, num_heads, num_kv_heads, md.max_decode_seq_len, block_size)
+        parts = max((md.max_decode_seq_len + md.partition_size - 1) // md.partition_size, 1)
         if workspace is not None:
             md.exp_sums, md.max_logits, md.tmp_out = workspace.views(nd, parts)
         else:
@@ -187,7 +226,8 @@ def decode_attention(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torc
                      block_table: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
                      max_seq_len: int, alibi_slopes: Optional[torch.Tensor] = None,
                      kv_cache_dtype: str = "auto", k_scale: Optional[torch.Tensor] = None,
-                     v_scale: Optional[torch.Tensor] = None, use_v1: Optional[bool] = None) -> None:
+                     v_scale: Optional[torch.Tensor] = None, use_v1: Optional[bool] = None,
+                     partition_size: int = PARTITION_SIZE) -> None:
     """paged_attention_v1 or _v2, chosen like the upstream caller the reference plugs into
     (vllm/attention/ops/paged_attn.py, PagedAttention.forward_decode): v1 when the context is
     short enough for one workgroup's LDS and there is already enough parallelism without
@@ -203,7 +243,7 @@ def decode_attention(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torc
     else:
         ops.paged_attention_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache,
                                num_kv_heads, scale, block_table, seq_lens, block_size, max_seq_len,
-                               alibi_slopes, kv_cache_dtype, k_scale, v_scale)
+                               alibi_slopes, kv_cache_dtype, k_scale, v_scale, partition_size=partition_size)
 
 
 def decode_attention_fused(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torch.Tensor,
@@ -211,7 +251,8 @@ def decode_attention_fused(out: torch.Tensor, exp_sums: torch.Tensor, max_logits
                            positions: torch.Tensor, cos_sin_cache: torch.Tensor, slot_mapping: torch.Tensor,
                            key_cache: torch.Tensor, value_cache: torch.Tensor, num_heads: int, num_kv_heads: int,
                            scale: float, block_table: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
-                           max_seq_len: int, use_v1: Optional[bool] = None) -> bool:
+                           max_seq_len: int, use_v1: Optional[bool] = None,
+                           partition_size: int = PARTITION_SIZE) -> bool:
     """qkv_rope_cache + decode_attention in one launch (MI355X-side fusion, include/mi355x_hotpath.h), with the
     same v1 / v2 choice as decode_attention.  False: not applicable to these shapes, nothing was launched."""
     head_size = key_cache.shape[2] * key_cache.shape[4]
@@ -221,7 +262,7 @@ def decode_attention_fused(out: torch.Tensor, exp_sums: torch.Tensor, max_logits
     return ops.paged_attention_fused_qkv(out, exp_sums, max_logits, tmp_out, qkv, slabs, sk, positions,
                                          cos_sin_cache, slot_mapping, key_cache, value_cache, num_heads,
                                          num_kv_heads, scale, block_table, seq_lens, block_size, max_seq_len,
-                                         not use_v1)
+                                         not use_v1, partition_size)
 
 
 def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
@@ -250,7 +291,7 @@ def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
         decode_attention(output[:ndt], md.exp_sums, md.max_logits, md.tmp_out, query[:ndt],
                          key_cache, value_cache, num_kv_heads, scale, md.block_table[:nd],
                          md.seq_lens[:nd], block_size, md.max_decode_seq_len, alibi_slopes,
-                         kv_cache_dtype, k_scale, v_scale, md.use_v1)
+                         kv_cache_dtype, k_scale, v_scale, md.use_v1, md.partition_size)
     if md.num_prefills > 0:
         ops.paged_prefill_attention(output[ndt:n], query[ndt:n], key_cache, value_cache,
                                     num_kv_heads, scale, md.block_table[nd:], md.seq_lens[nd:],

@@ -184,7 +184,10 @@ static int launch_norm(void* out, T* input, int64_t input_stride, T* residual,
   if (threads > need) threads = need;
   auto chunks = [&](int t) { return (units + t - 1) / t; };
   const int maxc = vec ? 4 : 32;
-  while (chunks(threads) > maxc && threads < 1024) threads *= 2;
+  // four 16-byte chunks per thread (hidden 8192 at 256 threads) need 128 VGPRs + 9-10 spilled: two chunks at twice
+  // the threads fit (101) — Llama-3-70B / Qwen2-72B prefill norms ran at 38 % of the HBM roofline with the spills
+  // (profiles/r03_rank_of_8_70b_fp8.json)
+  while (chunks(threads) > (vec ? 2 : maxc) && threads < 1024) threads *= 2;
   if (threads > 1024) threads = 1024;
   MI355X_REQUIRE(chunks(threads) <= maxc, MI355X_EUNSUPPORTED,
                  "%s: hidden_size %d too large (max %d)", name, hidden, maxc * 1024 * (vec ? V : 1));

@@ -40,7 +40,7 @@ namespace mi355x {
 
 constexpr int kPaThreads = 256;       // default workgroup: 4 waves
 constexpr int kPaMaxThreads = 512;    // few-workgroup launches (v1 at small batch) use 8 waves
-constexpr int kPaScratchBytes = 256;  // red[GT <= 4][16] floats
+constexpr int pa_scratch_bytes(int gt) { return gt > 4 ? 512 : 256; }  // red[GT][16] floats
 
 // 16-byte load of a K / V piece: non-temporal — the cache is streamed once per step, keeping it out of
 // L2 / MALL is worth 10 % (64 seqs x ctx 1088, v1: 54.3 -> 48.5 us, fp8 cache 34.8 -> 30.5 us;
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // all LDS lives in the dynamic region so that its base stays 16-B aligned
   float* red = reinterpret_cast<float*>(smem);                          // [GT][16]
+  constexpr int kPaScratchBytes = pa_scratch_bytes(GT);
   T* q_s = reinterpret_cast<T*>(smem + kPaScratchBytes);                // [GT][256]
   float* logits =
       reinterpret_cast<float*>(smem + kPaScratchBytes + (size_t)GT * 256 * sizeof(T));  // [GT][cap]
@@ -392,17 +393,23 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
   for (int g = 0; g < GT; ++g) qk_max[g] = -3.402823466e+38f;
 
   if constexpr (HS != 0) {
-    // q chunks of this lane live in registers for the whole kernel
-    uint4 qreg[GT][NI][QP];
+    // q chunks of this lane live in registers for the whole kernel — up to 4 heads per workgroup.  GT = 8 (one
+    // workgroup for ALL 8 query heads of a kv head: the TP = 8 shards of Llama-3-70B / Qwen2-72B, 8 q / 1 kv head)
+    // would need 128 VGPRs for them: there the chunks are re-read from LDS per K piece (the lanes of a token
+    // group read one address: a broadcast, 8 ds_read_b128 per 16-byte piece of K against 32 v_dot2c).
+    constexpr bool QLDS = GT > 4;
+    uint4 qreg[QLDS ? 1 : GT][NI][QP];
+    if constexpr (!QLDS) {
 #pragma unroll
-    for (int g = 0; g < GT; ++g) {
+      for (int g = 0; g < GT; ++g) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int c = csub + LPT * i;
+        for (int i = 0; i < NI; ++i) {
+          const int c = csub + LPT * i;
 #pragma unroll
-        for (int p = 0; p < QP; ++p) {
-          qreg[g][i][p] = (c < C) ? *reinterpret_cast<const uint4*>(q_s + g * D + c * X + p * XT)
-                                  : make_uint4(0, 0, 0, 0);
+          for (int p = 0; p < QP; ++p) {
+            qreg[g][i][p] = (c < C) ? *reinterpret_cast<const uint4*>(q_s + g * D + c * X + p * XT)
+                                    : make_uint4(0, 0, 0, 0);
+          }
         }
       }
     }
@@ -414,8 +421,21 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
       for (int j = 0; j < NI; ++j) {
         uint4 t[QP];                      // the piece as scalar_t (converted once, used by GT heads)
         Piece<T, CT>::cvt(kk[j], t);
+        if constexpr (QLDS) {
+          const int c = csub + LPT * j;
+          if (c < C) {
 #pragma unroll
-        for (int g = 0; g < GT; ++g) acc[g] = Piece<T, CT>::dot(t, qreg[g][j], acc[g]);
+            for (int g = 0; g < GT; ++g) {
+              uint4 qv[QP];
+#pragma unroll
+              for (int p = 0; p < QP; ++p) qv[p] = *reinterpret_cast<const uint4*>(q_s + g * D + c * X + p * XT);
+              acc[g] = Piece<T, CT>::dot(t, qv, acc[g]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < GT; ++g) acc[g] = Piece<T, CT>::dot(t, qreg[g][j], acc[g]);
+        }
       }
 #pragma unroll
       for (int g = 0; g < GT; ++g) {
@@ -703,7 +723,7 @@ static PaPlan pa_plan(int num_seqs, int num_heads, int num_kv_heads, int head_si
                       int elt_size, int max_seq_len, int partition_size) {
   PaPlan p;
   const int q_per_kv = num_heads / num_kv_heads;
-  p.gt = q_per_kv >= 3 ? 4 : q_per_kv;  // 1, 2 or 4 heads per workgroup
+  p.gt = q_per_kv >= 5 ? 8 : (q_per_kv >= 3 ? 4 : q_per_kv);  // 1, 2, 4 or 8 heads per workgroup
   p.tiles = (q_per_kv + p.gt - 1) / p.gt;
   const int padded_len = ((max_seq_len + block_size - 1) / block_size) * block_size;
   p.logits_cap = partition_size > 0 ? partition_size : padded_len;
@@ -718,7 +738,7 @@ static PaPlan pa_plan(int num_seqs, int num_heads, int num_kv_heads, int head_si
   if (p.logits_cap < min_cap) p.logits_cap = min_cap;
   p.logits_cap = (p.logits_cap + 63) & ~63;
   // + the block ids of the (sequence, partition): logits_cap / block_size ints
-  p.smem = kPaScratchBytes + (size_t)p.gt * 256 * elt_size + (size_t)p.gt * p.logits_cap * (4 + elt_size) +
+  p.smem = pa_scratch_bytes(p.gt) + (size_t)p.gt * 256 * elt_size + (size_t)p.gt * p.logits_cap * (4 + elt_size) +
            (size_t)(p.logits_cap / block_size) * 4;
   return p;
 }
@@ -761,6 +781,8 @@ static int launch_pa_bs(const PaArgs& a) {
     if constexpr (BS == 16 && sizeof(T) == 2 && std::is_same<T, CT>::value) {
       if (fast && p.gt == 4 && p.tiles == 1 && a.num_heads / a.num_kv_heads == 4)
         return launch_pa_inst<T, CT, BS, 4, 128, true>(a, p.tiles, p.num_parts, p.logits_cap, p.smem, p.threads);
+      if (fast && p.gt == 8 && p.tiles == 1 && a.num_heads / a.num_kv_heads == 8)
+        return launch_pa_inst<T, CT, BS, 8, 128, true>(a, p.tiles, p.num_parts, p.logits_cap, p.smem, p.threads);
     }
     return 1;   // not applicable: the caller runs qkv_rope_cache + paged_attention
   }
@@ -777,6 +799,7 @@ static int launch_pa_bs(const PaArgs& a) {
   PA_CASE(1)
   PA_CASE(2)
   PA_CASE(4)
+  PA_CASE(8)
 #undef PA_CASE
   set_error("paged_attention: internal dispatch error");
   return MI355X_EINVAL;
@@ -868,8 +891,8 @@ int mi355x_paged_attention_fused_qkv(
                  "paged_attention_fused_qkv: null pointer");
   MI355X_REQUIRE(partition_size == 0 || (exp_sums && max_logits && tmp_out), MI355X_EINVAL,
                  "paged_attention_fused_qkv: the partitioned form needs exp_sums / max_logits / tmp_out");
-  MI355X_REQUIRE(partition_size == 0 || partition_size == MI355X_PA_PARTITION_SIZE, MI355X_EINVAL,
-                 "paged_attention_fused_qkv: partition_size must be 0 or %d", MI355X_PA_PARTITION_SIZE);
+  MI355X_REQUIRE(partition_size % 16 == 0, MI355X_EINVAL,
+                 "paged_attention_fused_qkv: partition_size must be 0 or a multiple of the block size (16)");
   MI355X_REQUIRE(((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(slabs) |
                    reinterpret_cast<uintptr_t>(cos_sin_cache) | reinterpret_cast<uintptr_t>(key_cache)) & 15) == 0 &&
                      qkv_stride % 8 == 0,
@@ -880,13 +903,13 @@ int mi355x_paged_attention_fused_qkv(
   rc = dtype == MI355X_BF16 ? launch_pa<bf16_t>(a) : launch_pa<f16_t>(a);
   if (rc != MI355X_OK || partition_size == 0) return rc;
   // partitioned: the same reduce as paged_attention_v2
-  const int max_parts = (max_seq_len + MI355X_PA_PARTITION_SIZE - 1) / MI355X_PA_PARTITION_SIZE;
+  const int max_parts = (max_seq_len + partition_size - 1) / partition_size;
   return MI355X_DISPATCH_HALF(dtype, [&] {
     hipLaunchKernelGGL(paged_attention_reduce_kernel<scalar_t>, dim3(num_heads, num_seqs),
                        dim3(128), (size_t)(max_parts > 0 ? max_parts : 1) * sizeof(float), a.stream,
                        static_cast<scalar_t*>(out), exp_sums, max_logits,
                        static_cast<const scalar_t*>(tmp_out), seq_lens, head_size, max_parts,
-                       MI355X_PA_PARTITION_SIZE);
+                       partition_size);
     return check_launch("paged_attention_fused_qkv_reduce");
   });
 }
@@ -901,7 +924,7 @@ int mi355x_paged_attention_v1_max_seq_len(int num_seqs, int num_heads, int num_k
   const int esz = dtype_size(dtype);
   const PaPlan p = pa_plan(num_seqs > 0 ? num_seqs : 1, num_heads, num_kv_heads, head_size, block_size,
                            esz, block_size, 0);
-  const size_t fixed = kPaScratchBytes + (size_t)p.gt * 256 * esz;
+  const size_t fixed = pa_scratch_bytes(p.gt) + (size_t)p.gt * 256 * esz;
   // per token: gt * (fp32 logit + scalar_t probability) + 4 / block_size bytes of block id
   int64_t cap = (int64_t)((kPaLdsLimit - fixed) * block_size / ((size_t)p.gt * (4 + esz) * block_size + 4));
   cap &= ~(int64_t)63;                       // the launcher rounds the logits capacity up to 64
@@ -926,6 +949,42 @@ int mi355x_paged_attention_v1(void* out, const void* query, const void* key_cach
   return MI355X_DISPATCH_FLOAT(dtype, [&] { return launch_pa<scalar_t>(a); });
 }
 
+int mi355x_paged_attention_v2_ps(void* out, float* exp_sums, float* max_logits,
+                                 void* tmp_out, const void* query, const void* key_cache,
+                                 const void* value_cache, int num_seqs, int num_heads,
+                                 int num_kv_heads, int head_size, int block_size,
+                                 float scale, const int* block_tables,
+                                 const int* seq_lens, int max_num_blocks_per_seq,
+                                 int max_seq_len, const float* alibi_slopes,
+                                 int64_t q_stride, int64_t kv_block_stride,
+                                 int64_t kv_head_stride, int dtype, int kv_cache_dtype,
+                                 const float* k_scale, const float* v_scale, int partition_size,
+                                 mi355x_stream stream) {
+  MI355X_REQUIRE(partition_size > 0 && block_size > 0 && partition_size % block_size == 0 && partition_size % 16 == 0,
+                 MI355X_EINVAL, "paged_attention_v2: partition_size %d must be a positive multiple of the block size "
+                 "and of 16", partition_size);
+  PaArgs a{out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs,
+           num_heads, num_kv_heads, head_size, block_size, scale, block_tables, seq_lens,
+           max_num_blocks_per_seq, max_seq_len, alibi_slopes, q_stride, kv_block_stride,
+           kv_head_stride, partition_size, static_cast<hipStream_t>(stream),
+           kv_cache_dtype, k_scale, v_scale};
+  int rc = validate_pa(a, "paged_attention_v2");
+  if (rc || num_seqs == 0) return rc;
+  MI355X_REQUIRE(exp_sums && max_logits && tmp_out, MI355X_EINVAL,
+                 "paged_attention_v2: null workspace pointer");
+  rc = MI355X_DISPATCH_FLOAT(dtype, [&] { return launch_pa<scalar_t>(a); });
+  if (rc) return rc;
+  const int max_parts = (max_seq_len + partition_size - 1) / partition_size;
+  return MI355X_DISPATCH_FLOAT(dtype, [&] {
+    hipLaunchKernelGGL(paged_attention_reduce_kernel<scalar_t>, dim3(num_heads, num_seqs),
+                       dim3(128), (size_t)(max_parts > 0 ? max_parts : 1) * sizeof(float), a.stream,
+                       static_cast<scalar_t*>(out), exp_sums, max_logits,
+                       static_cast<const scalar_t*>(tmp_out), seq_lens, head_size, max_parts,
+                       partition_size);
+    return check_launch("paged_attention_v2_reduce");
+  });
+}
+
 int mi355x_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
                               void* tmp_out, const void* query, const void* key_cache,
                               const void* value_cache, int num_seqs, int num_heads,
@@ -936,26 +995,11 @@ int mi355x_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
                               int64_t q_stride, int64_t kv_block_stride,
                               int64_t kv_head_stride, int dtype, int kv_cache_dtype,
                               const float* k_scale, const float* v_scale, mi355x_stream stream) {
-  PaArgs a{out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs,
-           num_heads, num_kv_heads, head_size, block_size, scale, block_tables, seq_lens,
-           max_num_blocks_per_seq, max_seq_len, alibi_slopes, q_stride, kv_block_stride,
-           kv_head_stride, MI355X_PA_PARTITION_SIZE, static_cast<hipStream_t>(stream),
-           kv_cache_dtype, k_scale, v_scale};
-  int rc = validate_pa(a, "paged_attention_v2");
-  if (rc || num_seqs == 0) return rc;
-  MI355X_REQUIRE(exp_sums && max_logits && tmp_out, MI355X_EINVAL,
-                 "paged_attention_v2: null workspace pointer");
-  rc = MI355X_DISPATCH_FLOAT(dtype, [&] { return launch_pa<scalar_t>(a); });
-  if (rc) return rc;
-  const int max_parts = (max_seq_len + MI355X_PA_PARTITION_SIZE - 1) / MI355X_PA_PARTITION_SIZE;
-  return MI355X_DISPATCH_FLOAT(dtype, [&] {
-    hipLaunchKernelGGL(paged_attention_reduce_kernel<scalar_t>, dim3(num_heads, num_seqs),
-                       dim3(128), (size_t)(max_parts > 0 ? max_parts : 1) * sizeof(float), a.stream,
-                       static_cast<scalar_t*>(out), exp_sums, max_logits,
-                       static_cast<const scalar_t*>(tmp_out), seq_lens, head_size, max_parts,
-                       MI355X_PA_PARTITION_SIZE);
-    return check_launch("paged_attention_v2_reduce");
-  });
+  return mi355x_paged_attention_v2_ps(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache, num_seqs,
+                                      num_heads, num_kv_heads, head_size, block_size, scale, block_tables, seq_lens,
+                                      max_num_blocks_per_seq, max_seq_len, alibi_slopes, q_stride, kv_block_stride,
+                                      kv_head_stride, dtype, kv_cache_dtype, k_scale, v_scale,
+                                      MI355X_PA_PARTITION_SIZE, stream);
 }
 
 }  // extern "C"

@@ -88,6 +88,34 @@ __device__ __forceinline__ uint4 dequant_word(uint32_t w, float s, float zs) {
   return r;
 }
 
+// The same value from half as many converts: a byte 0x0q read as OCP e4m3 is q * 2^-9 for every q in 0..15 (the
+// nibble's top bit lands in the exponent field, the denormal range continues linearly into the first binade), so one
+// v_cvt_pk_f32_fp8 turns two masked nibbles into two floats.  s512 = 512 * s: (q 2^-9) (512 s) is the same real
+// number as q s, the fma rounds once — bit-identical to dequant_word (scripts/ubench/valu_rate.hip prints the
+// identity and the issue rates).
+template <typename T>
+__device__ __forceinline__ uint4 dequant_word_fp8pk(uint32_t w, float s512, float zs) {
+  const uint32_t t0 = w & 0x0F0F0F0Fu;         // bytes: k0, k4, k1, k5
+  const uint32_t t1 = (w >> 4) & 0x0F0F0F0Fu;  // bytes: k2, k6, k3, k7
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t k04, k15, k26, k37;
+  asm("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_0" : "=v"(k04) : "v"(t0));
+  asm("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_1" : "=v"(k15) : "v"(t0));
+  asm("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_0" : "=v"(k26) : "v"(t1));
+  asm("v_cvt_pk_f32_fp8_sdwa %0, %1 src0_sel:WORD_1" : "=v"(k37) : "v"(t1));
+  auto f = [&](float q) {
+    float r;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(q), "v"(s512), "v"(zs));
+    return r;
+  };
+  uint4 r;
+  r.x = Mfma<T>::pack(f(k04.x), f(k15.x));
+  r.y = Mfma<T>::pack(f(k26.x), f(k37.x));
+  r.z = Mfma<T>::pack(f(k04.y), f(k15.y));
+  r.w = Mfma<T>::pack(f(k26.y), f(k37.y));
+  return r;
+}
+
 enum ZeroMode { kZeroAwq = 0, kZeroGptq = 1 };
 
 // zero points of the 4 columns n .. n+3 (n % 4 == 0) from their packed word

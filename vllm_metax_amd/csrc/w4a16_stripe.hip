@@ -33,6 +33,36 @@
 
 namespace mi355x {
 
+// -DSTRIPE_DQ=n: dequant experiments (scripts/build_variant.sh): 0 = v_cvt_f32_ubyteN per weight (default),
+// 1 = v_cvt_pk_f32_fp8 per weight pair (bit-identical), 2 = TIMING ONLY, WRONG VALUES: the 7-op 0x4300 | q conversion
+// with no scale / zero applied at all = a lower bound for any "scale after the MMA" scheme in this loop structure
+#ifndef STRIPE_DQ
+#define STRIPE_DQ 0
+#endif
+// ring depths in stages (-DSTRIPE_WD / -DSTRIPE_AD for experiments)
+#ifndef STRIPE_WD
+#define STRIPE_WD 3
+#endif
+#ifndef STRIPE_AD
+#define STRIPE_AD 3
+#endif
+#if STRIPE_DQ == 1
+#define STRIPE_DEQUANT(w, s, zs) dequant_word_fp8pk<T>(w, s, zs)
+#elif STRIPE_DQ == 2
+__device__ __forceinline__ uint4 magic_word_no_scale(uint32_t w, float s, float zs) {
+  const uint32_t m = 0x000F000Fu, c = 0x43004300u + (__builtin_bit_cast(uint32_t, s) & 1u) + (__builtin_bit_cast(uint32_t, zs) & 1u);
+  uint4 r;
+  r.x = (w & m) | c;
+  r.y = ((w >> 4) & m) | c;
+  r.z = ((w >> 8) & m) | c;
+  r.w = ((w >> 12) & m) | c;
+  return r;
+}
+#define STRIPE_DEQUANT(w, s, zs) magic_word_no_scale(w, s, zs)
+#else
+#define STRIPE_DEQUANT(w, s, zs) dequant_word<T>(w, s, zs)
+#endif
+
 constexpr double STRIPE_T256 = 1.25;   // cost-model time of a 256-k stage relative to a 128-k stage (bk = 256 plans)
 
 // WV = waves per workgroup: 8 (stages of 128 k) or 16 (stages of 256 k, 4 waves per SIMD).  A wave's own
@@ -58,8 +88,8 @@ struct StripeCfg {
   static constexpr int A_BYTES = A_IMG_BYTES + SETS * SET_BYTES;  // A-ring slot: images + sets
   // ring depths: the weight stream comes from HBM (~2-3 us under load) and needs >= 48 KiB in
   // flight per CU; activations / scales come from L2 and need two stages ahead.
-  static constexpr int W_DEPTH = 3;
-  static constexpr int A_DEPTH = 3;
+  static constexpr int W_DEPTH = STRIPE_WD;
+  static constexpr int A_DEPTH = STRIPE_AD;
   static constexpr int WAVES_PER_SIMD = WV / 4;
   static constexpr int W_COPIES = NW;            // per weight-loader wave (waves 0-3) and stage
   static constexpr int A_COPIES = MT + 1;        // per activation-loader wave (4-7): images + one set
@@ -313,18 +343,21 @@ __global__ __launch_bounds__((StripeCfg<MT, NW, SETS, WV>::THREADS)) void w4a16_
       for (int t = 0; t < 4; ++t) {
         scf[q][t] = to_f32(sct[t]);
         zsf[q][t] = -zp[t] * scf[q][t];
+#if STRIPE_DQ == 1
+        scf[q][t] *= 512.f;   // dequant_word_fp8pk takes 512 s
+#endif
       }
     }
     auto word_of = [&](int j) {
       const int q = j >> 2, t = j & 3;
       return t == 0 ? wq[q].x : (t == 1 ? wq[q].y : (t == 2 ? wq[q].z : wq[q].w));
     };
-    uint4 bf_cur = dequant_word<T>(word_of(0), scf[0][0], zsf[0][0]);
+    uint4 bf_cur = STRIPE_DEQUANT(word_of(0), scf[0][0], zsf[0][0]);
 #pragma unroll
     for (int j = 0; j < NWORDS; ++j) {
       const int q = j >> 2, t = j & 3;
       uint4 bf_nxt = bf_cur;
-      if (j + 1 < NWORDS) bf_nxt = dequant_word<T>(word_of(j + 1), scf[(j + 1) >> 2][(j + 1) & 3], zsf[(j + 1) >> 2][(j + 1) & 3]);
+      if (j + 1 < NWORDS) bf_nxt = STRIPE_DEQUANT(word_of(j + 1), scf[(j + 1) >> 2][(j + 1) & 3], zsf[(j + 1) >> 2][(j + 1) & 3]);
 #pragma unroll
       for (int i = 0; i < MT; ++i) acc[i][t] = Mfma<T>::run(af[q][i], bf_cur, acc[i][t]);
       if (j + 1 < NWORDS) {

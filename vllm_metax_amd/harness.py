@@ -22,7 +22,7 @@ from typing import List, Optional
 import torch
 
 from . import _custom_ops as ops
-from .attention.backend import decode_attention, decode_attention_fused
+from .attention.backend import decode_attention, decode_attention_fused, decode_partition_size
 
 
 @dataclasses.dataclass
@@ -519,7 +519,10 @@ class HotPathModel:
         self.d_slots = self._slots(self.d_seq_ids, self.d_positions)   # slot the next decode step writes
         self.d_max_seq_len = max_seq_len
         H = self.layers[0].q_heads
-        P = (max_seq_len + ops.PARTITION_SIZE - 1) // ops.PARTITION_SIZE
+        # split-KV partition size of the v2 launch: 512 as in the reference, finer when (sequences x kv heads) alone
+        # leaves CUs without a workgroup (a TP = 8 rank: 1 kv head) — attention/backend.py::decode_partition_size
+        self.d_partition = decode_partition_size(num_seqs, H, self.layers[0].kv_heads, max_seq_len, self.BLOCK)
+        P = (max_seq_len + self.d_partition - 1) // self.d_partition
         self.d_tmp = torch.empty(num_seqs, H, P, self.cfg.head_dim, dtype=self.dtype, device=dev)
         self.d_es = torch.empty(num_seqs, H, P, dtype=torch.float32, device=dev)
         self.d_ml = torch.empty_like(self.d_es)
@@ -541,7 +544,7 @@ class HotPathModel:
             decode_attention(out, self.d_es, self.d_ml, self.d_tmp, q3, self.k_cache[i],
                              self.v_cache[i], self.layers[i].kv_heads, self.scale, self.d_bt,
                              self.d_seq_lens, self.BLOCK, self.d_max_seq_len, None, self.kv_dtype,
-                             self.k_scale, self.v_scale)
+                             self.k_scale, self.v_scale, partition_size=self.d_partition)
             return out
 
         def attn_fused_fn(i, qkv, slabs, sk):
@@ -550,7 +553,7 @@ class HotPathModel:
             ok = decode_attention_fused(out, self.d_es, self.d_ml, self.d_tmp, qkv, slabs, sk, self.d_positions,
                                         self.cos_sin, slots, self.k_cache[i], self.v_cache[i], L.q_heads,
                                         L.kv_heads, self.scale, self.d_bt, self.d_seq_lens, self.BLOCK,
-                                        self.d_max_seq_len)
+                                        self.d_max_seq_len, partition_size=self.d_partition)
             return out if ok else None
 
         pending = (None, 0)
