@@ -174,13 +174,16 @@ def instrument(model, timer: EventTimer):
             timer.discard_last(name)     # fused path not taken: the caller times the plain GEMM
         return out
 
-    def timed_deferred(self, x):
+    def timed_deferred(self, x, allow_scaled=False):
         m = x.shape[0]
-        if not (self.quant == "awq" and m <= 64):
-            return orig_def(self, x)     # falls through to __call__, which is timed
+        own = (self.quant == "awq" and m <= 64) or \
+            (self.quant == "fp8" and m <= 64 and allow_scaled and harness.QLinear.fp8_defer)
+        if not own:
+            return orig_def(self, x, allow_scaled)     # falls through to __call__, which is timed
         flops = 2.0 * m * self.n * self.k
         nbytes = self.weight_bytes() + 2.0 * m * self.k + 2.0 * m * self.n
-        return timer.time(f"{self.quant}_gemm_small_m", flops, nbytes, lambda: orig_def(self, x))
+        # (fp8 with an un-quantised input: the record then includes its per-token quant launch, as __call__'s does)
+        return timer.time(f"{self.quant}_gemm_small_m", flops, nbytes, lambda: orig_def(self, x, allow_scaled))
 
     harness.QLinear.silu_mul = timed_silu
     harness.QLinear.deferred = timed_deferred
@@ -247,6 +250,11 @@ def instrument(model, timer: EventTimer):
          lambda out, inp, sc, ub=None: (0.0, float(inp.numel() * inp.element_size() + out.numel())))
     wrap("silu_and_mul_per_token_quant", lambda inp: (0.0, float(inp.numel() * inp.element_size() + inp.numel() // 2)),
          record_as="silu_and_mul")
+    wrap("silu_and_mul_per_token_quant_slabs",
+         lambda slabs, sk, a_s, b_s, n, d, dt: (0.0, float(n * d * (8.0 * sk + 1))), record_as="silu_and_mul")
+    wrap("rms_norm_dynamic_per_token_quant_slabs",
+         lambda out, slabs, sk, *a, **k: (0.0, float(out.numel() * (4.0 * sk + 1 + 4))),
+         record_as="rms_norm_dynamic_per_token_quant")
     wrap("greedy_advance", lambda logits, *a, **k: (0.0, float(logits.numel() * logits.element_size())))
     wrap("rotary_reshape_and_cache",
          lambda pos, key, value, kc, *a, **k: (0.0, 2.0 * key.numel() * (2 + kc.element_size())),

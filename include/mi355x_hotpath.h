@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 5   /* 5: + paged_attention_v2_ps (additive); 4: + paged_prefill_attention_alibi, silu_and_mul_per_token_quant (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
+#define MI355X_ABI_VERSION 5   /* 5: + paged_attention_v2_ps, scaled_mm_fp8_deferred and its slab consumers (additive); 4: + paged_prefill_attention_alibi, silu_and_mul_per_token_quant (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
                                 * 2 was BREAKING (kv_cache_dtype / k_scale / v_scale inserted before `stream` in reshape_and_cache*,
                                 * paged_attention_v1/_v2, paged_prefill_attention): a binding must refuse a library whose
                                 * mi355x_abi_version() differs from the version it was written for (vllm_metax_amd/_abi.py does) */
@@ -518,8 +518,8 @@ int mi355x_paged_prefill_attention_image(
  * qkv row (sk == 0) or its split-K slabs, applies the NeoX rotary to q and k, writes k / v into the cache slot
  * and runs paged_attention_v1 (partition_size 0) or _v2 (partition_size 512 + the reduce launch) on q.
  * Bit-identical to mi355x_qkv_rope_cache + mi355x_paged_attention_v1/_v2 (out and caches; the qkv buffer
- * itself is NOT updated).  Applies to 2-byte dtypes, head_size 128, block_size 16, x 8, 4 query heads per
- * kv head, scalar_t caches; otherwise returns 1 (no error): run the two calls instead. */
+ * itself is NOT updated).  Applies to 2-byte dtypes, head_size 128, block_size 16, x 8, 4 or 8 query heads per
+ * kv head (one workgroup per kv head), scalar_t caches; otherwise returns 1 (no error): run the two calls instead. */
 int mi355x_paged_attention_fused_qkv(
     void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* qkv, int64_t qkv_stride,
     const float* slabs, int sk, const int64_t* positions, const void* cos_sin_cache,
@@ -557,6 +557,46 @@ int mi355x_scaled_mm_fp8(void* out, const void* a, const void* b, const float* a
                          const void* bias, float* workspace, int64_t workspace_elems, int m,
                          int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype,
                          mi355x_stream stream);
+
+/* ---- fp8 decode step: the K split of a scaled GEMM reduced by its consumer (round 3; no reference ops) --------
+ * Decode-sized (m <= 64) W8A8 GEMMs are launch-latency-bound: every launch of the fp8 decoder layer
+ * costs ~4.7 us whatever it does.  mi355x_scaled_mm_fp8_deferred is mi355x_scaled_mm_fp8 (no bias) that leaves a K
+ * split as fp32 partial slabs workspace[sk][m][n] (*sk_out = sk > 1) instead of launching its finish kernel;
+ * *sk_out = 0: `out` is final.  The consumers below then compute T(sum of slabs * a_scale[row] * b_scale[col]) —
+ * the finish kernel's bits — on their way in; each is tested bit for bit against the unfused op sequence. */
+int mi355x_scaled_mm_fp8_deferred(void* out, const void* a, const void* b, const float* a_scales,
+                                  int a_scales_numel, const float* b_scales, int b_scales_numel,
+                                  float* workspace, int64_t workspace_elems, int m, int n, int k,
+                                  int64_t lda, int64_t ldb, int64_t ldc, int out_dtype, int* sk_out,
+                                  mi355x_stream stream);
+/* mi355x_paged_attention_fused_qkv whose qkv slabs come from an fp8 GEMM (a_scales [num_seqs] or [1], b_scales
+ * [(num_heads + 2 num_kv_heads) * head_size] or [1]; b_scales NULL = plain slabs / row), and — out_q != NULL,
+ * partitioned form only, <= 16 heads, <= 64 partitions — whose reduce launch also quantises the attention output
+ * per token (out_q e4m3 [num_seqs, num_heads * head_size], out_scales float [num_seqs]: the bits of
+ * dynamic_per_token_scaled_fp8_quant on the reduce's output, the input of an fp8 o_proj; `out` is then unused).
+ * Returns 1 when not applicable. */
+int mi355x_paged_attention_fused_qkv_w8(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* qkv, int64_t qkv_stride,
+    const float* slabs, int sk, const int64_t* positions, const void* cos_sin_cache,
+    const int64_t* slot_mapping, void* key_cache, void* value_cache, int num_seqs, int num_heads,
+    int num_kv_heads, int head_size, int block_size, int x, float scale, const int* block_tables,
+    const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len, int64_t kv_block_stride,
+    int64_t kv_head_stride, int partition_size, int dtype, const float* a_scales, int a_scales_numel,
+    const float* b_scales, int b_scales_numel, void* out_q, float* out_scales, mi355x_stream stream);
+/* silu_and_mul_per_token_quant on the slabs [sk][num_tokens][2 d] of an fp8 gate_up GEMM.  Returns 1 when not
+ * applicable (d % 8, d > 16384, alignment). */
+int mi355x_silu_and_mul_per_token_quant_slabs(void* out, float* scales, const float* slabs, int sk,
+                                              const float* a_scales, int a_scales_numel,
+                                              const float* b_scales, int b_scales_numel, int num_tokens, int d,
+                                              int dtype, mi355x_stream stream);
+/* rms_norm_dynamic_per_token_quant whose input rows are the slabs [sk][num_tokens][hidden_size] of an fp8 GEMM
+ * (o_proj / down_proj at TP = 1); residual (fused add) as in the op itself. */
+int mi355x_rms_norm_dynamic_per_token_quant_slabs(void* out, const float* slabs, int sk,
+                                                  const float* a_scales, int a_scales_numel,
+                                                  const float* b_scales, int b_scales_numel,
+                                                  const void* weight, float* scales, float epsilon,
+                                                  const float* scale_ub, void* residual, int num_tokens,
+                                                  int hidden_size, int dtype, mi355x_stream stream);
 
 #ifdef __cplusplus
 }

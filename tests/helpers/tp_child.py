@@ -29,7 +29,7 @@ def main():
     if os.environ.get("TP_SWITCHES_OFF", "0") == "1":
         # every cross-op fusion of the harness off: the plain op sequence (read at import / construction time)
         for k in ("MI355X_PACKED_SILU", "MI355X_PREPACK", "MI355X_FUSE_GREEDY", "MI355X_FUSE_ATTN_QKV",
-                  "MI355X_NORM_IMAGE", "MI355X_FUSE_NORM_QUANT"):
+                  "MI355X_NORM_IMAGE", "MI355X_FUSE_NORM_QUANT", "MI355X_FP8_DEFER"):
             os.environ[k] = "0"
     from vllm_metax_amd import harness
     quant = os.environ.get("TP_QUANT", "awq")

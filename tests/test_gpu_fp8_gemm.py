@@ -141,3 +141,76 @@ def test_scaled_mm_llama8b_bench_shapes(kind, k, n, m):
         assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "not reproducible"
     else:   # fp8 decode split-K: fp32 atomics, order-dependent in the last bit
         assert_gemm_close(out2.cpu(), out.cpu(), "fp8 split-K repeat", max_frac=0.12)
+
+
+# ------------------------------------------------------------------ round 3: K split reduced by the consumer
+def _deferred_case(m, n, k, seed, out_dtype=torch.bfloat16):
+    """fp8 GEMM operands at a decode shape + the unfused result (cutlass_scaled_mm incl. its finish launch) and the
+    deferred form's slabs."""
+    d = dev()
+    a, b, a_s, b_s, _ = _mk(m, n, k, True, True, False, out_dtype, seed)
+    a, b, a_s, b_s = a.to(d), b.t().contiguous().to(d).t(), a_s.to(d), b_s.to(d)
+    ref = torch.empty(m, n, dtype=out_dtype, device=d)
+    ops().cutlass_scaled_mm(ref, a, b, a_s, b_s, None)
+    ws = torch.full((16 * m * n,), float("nan"), dtype=torch.float32, device=d)
+    out = torch.full((m, n), float("nan"), dtype=out_dtype, device=d)
+    sk = ops().scaled_mm_fp8_deferred(out, a, b, a_s, b_s, ws)
+    return ref, out, ws, sk, a_s, b_s
+
+
+@pytest.mark.parametrize("shape", [(64, 1280, 8192), (64, 7168, 8192), (64, 8192, 3584), (64, 4096, 14336),
+                                   (17, 6144, 4096), (64, 28672, 4096), (64, 8192, 1024)])
+def test_scaled_mm_fp8_deferred_slabs_reduce_to_the_finished_output(shape):
+    """mi355x_scaled_mm_fp8_deferred: either `out` is final (sk == 0: bit-identical to cutlass_scaled_mm) or the
+    slabs [sk, m, n] reduce — sum in slab order, times the scales, one rounding — to exactly its output."""
+    m, n, k = shape
+    ref, out, ws, sk, a_s, b_s = _deferred_case(m, n, k, seed=3)
+    if sk == 0:
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+        return
+    assert 2 <= sk <= 16
+    slabs = ws[:sk * m * n].view(sk, m, n)
+    assert bool(torch.isfinite(slabs).all())
+    acc = slabs[0].clone()
+    for s_ in range(1, sk):
+        acc += slabs[s_]
+    got = (acc * a_s * b_s + 0.0).to(ref.dtype)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_silu_quant_on_slabs_is_bit_identical(dtype):
+    """silu_and_mul_per_token_quant_slabs == (finish launch of the gate_up GEMM) + silu_and_mul_per_token_quant."""
+    m, n, k = 64, 7168, 8192            # one TP = 8 rank of Llama-3-70B: gate_up [8192 -> 2 x 3584]
+    ref, out, ws, sk, a_s, b_s = _deferred_case(m, n, k, seed=5, out_dtype=dtype)
+    assert sk > 0, "this shape is expected to split K"
+    want_q, want_s = ops().silu_and_mul_per_token_quant(ref)
+    got = ops().silu_and_mul_per_token_quant_slabs(ws, sk, a_s, b_s, m, n // 2, dtype)
+    assert got is not None
+    assert torch.equal(got[1], want_s)
+    assert torch.equal(got[0].view(torch.uint8), want_q.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_norm_quant_on_slabs_is_bit_identical(dtype, with_residual):
+    """rms_norm_dynamic_per_token_quant_slabs == finish launch + rms_norm_dynamic_per_token_quant (o_proj / down_proj
+    of an fp8 model at TP = 1: hidden 4096, K = 14336)."""
+    m, n, k = 64, 4096, 14336
+    ref, out, ws, sk, a_s, b_s = _deferred_case(m, n, k, seed=7, out_dtype=dtype)
+    assert sk > 0
+    d = dev()
+    g = torch.Generator().manual_seed(1)
+    w = (torch.rand(n, generator=g) * 0.2 + 0.9).to(dtype).to(d)
+    res = (torch.randn(m, n, generator=g) * 0.5).to(dtype).to(d)
+    r1, r2 = (res.clone(), res.clone()) if with_residual else (None, None)
+    q1 = torch.empty(m, n, dtype=FP8, device=d)
+    s1 = torch.empty(m, 1, dtype=torch.float32, device=d)
+    ops().rms_norm_dynamic_per_token_quant(q1, ref, w, s1, 1e-5, None, r1)
+    q2 = torch.empty_like(q1)
+    s2 = torch.empty_like(s1)
+    ops().rms_norm_dynamic_per_token_quant_slabs(q2, ws, sk, a_s, b_s, w, s2, 1e-5, None, r2)
+    assert torch.equal(s1, s2)
+    assert torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
+    if with_residual:
+        assert torch.equal(r1.view(torch.int16), r2.view(torch.int16))

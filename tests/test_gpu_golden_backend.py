@@ -414,3 +414,39 @@ def test_end_to_end_llama_width_w8a8_finite_and_oracle_tokens(quant):
         assert torch.equal(runs[0], runs[1])
     else:                    # fp8: same kernels, deterministic slab order -> identical as well
         assert torch.equal(runs[0], runs[1])
+
+
+@pytest.mark.parametrize("geom", ["llama-8b-width", "tp8-rank-heads"])
+def test_fp8_decode_consumer_side_reduction_is_bit_identical(geom):
+    """fp8 model decode with the K splits reduced by the consumers (scaled_mm_fp8_deferred -> fused-qkv attention /
+    silu + quant / norm + quant on the slabs, attention reduce + quant) against MI355X_FP8_DEFER=0 (every GEMM runs
+    its own finish launch, separate quant launch): the same logits bit for bit at every step, eager and graph.
+    Geometries: Llama-3-8B width (32 / 8 heads: v1 attention) and 8 q / 1 kv head at hidden 8192-like width
+    (partitioned attention + reduce-quant)."""
+    from vllm_metax_amd import harness
+    torch.manual_seed(0)
+    cfg = harness.ModelConfig.llama_geometry("fp8", layers=2, vocab=4096)
+    if geom == "tp8-rank-heads":
+        cfg.heads, cfg.kv_heads = 8, 1                  # one TP = 8 rank of a 64 / 8-head model, as a TP = 1 model
+    n, plen, steps = 5, 300, 3
+    if geom == "tp8-rank-heads":
+        plen = 600                                      # > 512 tokens and few (sequence, head) pairs: the v2 launch
+    tokens = torch.randint(0, cfg.vocab, (n, plen), device="cuda:0")
+    results = []
+    # (qkv -> attention + attention -> quant [the default], + the per-token row consumers [off by default], none)
+    for defer, rows in ((True, False), (True, True), (False, False)):
+        harness.QLinear.fp8_defer, harness.QLinear.fp8_defer_rows = defer, rows
+        try:
+            for use_graph in ((False, True) if defer else (False,)):
+                model = harness.HotPathModel(cfg, n, plen + 16, device="cuda:0", seed=0)
+                model.setup_decode(n, plen, plen + 16)
+                toks, logits = _serve(model, tokens, steps, use_graph)
+                results.append((toks, [lg.clone() for lg in logits]))
+        finally:
+            harness.QLinear.fp8_defer, harness.QLinear.fp8_defer_rows = True, False
+    base_t, base_l = results[-1]
+    for toks, logits in results[:-1]:
+        assert torch.equal(toks, base_t)
+        for a, b in zip(logits, base_l):
+            assert torch.equal(a, b)
+            assert bool(torch.isfinite(a).all())

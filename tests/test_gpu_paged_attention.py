@@ -390,3 +390,67 @@ def test_fused_qkv_attention_is_bit_identical(dtype, sk, partitioned, geom):
                                              slots, k4[:, :1], v3[:, :1], 10, 1, scale, bt, sl, BS, max_len,
                                              partitioned, PS)
     assert_bit_exact(k4, kc, "untouched")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("geom", [(8, 1, 288), (8, 2, 512), (32, 8, 512)])
+@pytest.mark.parametrize("quant_out", [False, True])
+def test_fused_qkv_w8_slabs_and_quantised_output_are_bit_identical(dtype, geom, quant_out):
+    """mi355x_paged_attention_fused_qkv_w8 (fp8 model decode, round 3): the qkv row arrives as the split-K slabs of an
+    fp8 GEMM with its scales still to apply, and the reduce launch may quantise the attention output per token.
+    Against the op sequence it replaces: T(slab sum x scales) [= the GEMM's finish launch] -> fused_qkv on that row
+    -> dynamic_per_token_scaled_fp8_quant."""
+    from vllm_metax_amd import _custom_ops as ops
+    H, KVH, PS = geom
+    D, BS, sk = 128, 16, 3
+    if quant_out and H > 16:
+        pytest.skip("the reduce + quant kernel serves <= 16 heads (one wave per head)")
+    lens = [1, 16, 17, 33, PS, PS + 1, 1100, 640]
+    n = len(lens)
+    g = torch.Generator().manual_seed(23)
+    max_len = max(lens)
+    nblk = (max_len + BS - 1) // BS
+    nb = n * nblk + 3
+    d = dev()
+    kc = (torch.randn(nb, KVH, D // 8, BS, 8, generator=g) * 0.5).to(dtype).to(d)
+    vc = (torch.randn(nb, KVH, D, BS, generator=g) * 0.5).to(dtype).to(d)
+    bt = torch.randperm(nb, generator=g)[:n * nblk].to(torch.int32).view(n, nblk).to(d)
+    sl = torch.tensor(lens, dtype=torch.int32, device=d)
+    pos = (sl - 1).to(torch.int64)
+    slots = (bt[torch.arange(n, device=d), (pos // BS)].long() * BS + pos % BS)
+    width = (H + 2 * KVH) * D
+    slabs = (torch.randn(sk, n, width, generator=g) * 30).to(d)
+    a_s = (torch.rand(n, 1, generator=g) * 9e-3 + 1e-3).to(d)
+    b_s = (torch.rand(1, width, generator=g) * 9e-3 + 1e-3).to(d)
+    cos_sin = torch.randn(2048, D, generator=g).to(dtype).to(d)
+    scale = D ** -0.5
+    P = (max_len + PS - 1) // PS
+    es = torch.empty(n, H, P, dtype=torch.float32, device=d)
+    ml = torch.empty_like(es)
+    tmp = torch.empty(n, H, P, D, dtype=dtype, device=d)
+    # unfused: the finished qkv row, then the fused-qkv attention on it (itself tested against its op sequence), then quant
+    acc = slabs[0].clone()
+    for i in range(1, sk):
+        acc += slabs[i]
+    qkv_ref = (acc * a_s * b_s + 0.0).to(dtype)
+    k2, v2 = kc.clone(), vc.clone()
+    ref = torch.empty(n, H, D, dtype=dtype, device=d)
+    assert ops.paged_attention_fused_qkv(ref, es, ml, tmp, qkv_ref, None, 0, pos, cos_sin, slots, k2, v2, H, KVH, scale,
+                                         bt, sl, BS, max_len, True, PS)
+    rq = torch.empty(n, H * D, dtype=torch.float8_e4m3fn, device=d)
+    rs = torch.empty(n, 1, dtype=torch.float32, device=d)
+    ops.dynamic_per_token_scaled_fp8_quant(rq, ref.view(n, H * D), rs, None)
+    # fused
+    k3, v3 = kc.clone(), vc.clone()
+    out = torch.full((n, H, D), float("nan"), dtype=dtype, device=d)
+    qo = (torch.empty_like(rq), torch.empty_like(rs)) if quant_out else None
+    dummy = torch.empty(n, width, dtype=dtype, device=d)
+    assert ops.paged_attention_fused_qkv(out, es, ml, tmp, dummy, slabs, sk, pos, cos_sin, slots, k3, v3, H, KVH, scale,
+                                         bt, sl, BS, max_len, True, PS, slab_scales=(a_s, b_s), quant_out=qo)
+    assert_bit_exact(k3, k2, "key cache")
+    assert_bit_exact(v3, v2, "value cache")
+    if quant_out:
+        assert torch.equal(qo[1], rs)
+        assert torch.equal(qo[0].view(torch.uint8), rq.view(torch.uint8))
+    else:
+        assert_bit_exact(out, ref, "attention output")

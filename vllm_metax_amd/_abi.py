@@ -102,6 +102,14 @@ PROTOTYPES = {
     "mi355x_dynamic_scaled_int8_quant": (_I, [_P, _P, _P, _I, _I, _L, _I, _P]),
     "mi355x_scaled_mm_fp8": (
         _I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _L, _I, _I, _I, _L, _L, _L, _I, _P]),
+    "mi355x_scaled_mm_fp8_deferred": (
+        _I, [_P, _P, _P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _L, _L, _L, _I, _P, _P]),
+    "mi355x_paged_attention_fused_qkv_w8": (
+        _I, [_P, _P, _P, _P, _P, _L, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P, _P, _I, _I, _L,
+             _L, _I, _I, _P, _I, _P, _I, _P, _P, _P]),
+    "mi355x_silu_and_mul_per_token_quant_slabs": (_I, [_P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "mi355x_rms_norm_dynamic_per_token_quant_slabs": (
+        _I, [_P, _P, _I, _P, _I, _P, _I, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

@@ -416,6 +416,28 @@ def rms_norm_dynamic_per_token_quant(out: torch.Tensor, input: torch.Tensor,
     _abi.check(rc, "rms_norm_dynamic_per_token_quant")
 
 
+def rms_norm_dynamic_per_token_quant_slabs(out: torch.Tensor, slabs: torch.Tensor, sk: int, a_scales: torch.Tensor,
+                                           b_scales: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor,
+                                           epsilon: float, scale_ub: Optional[torch.Tensor] = None,
+                                           residual: Optional[torch.Tensor] = None) -> None:
+    """rms_norm_dynamic_per_token_quant whose input rows are the split-K slabs [sk, tokens, hidden] (float32) of an
+    fp8 GEMM (scaled_mm_fp8_deferred; the GEMM's output type = weight.dtype): bit-identical to the GEMM's finish
+    launch followed by that op."""
+    _dev(out, slabs, a_scales, b_scales, weight, scales, scale_ub, residual)
+    _check_fp8(out)
+    hidden = out.size(-1)
+    num_tokens = out.numel() // hidden
+    if slabs.dtype != torch.float32 or slabs.numel() < sk * num_tokens * hidden or sk <= 0:
+        raise RuntimeError("rms_norm_dynamic_per_token_quant_slabs: slabs must be float32 [sk, tokens, hidden]")
+    if not out.is_contiguous() or scales.dtype != torch.float32:
+        raise RuntimeError("rms_norm_dynamic_per_token_quant_slabs: contiguous out, float32 scales")
+    rc = _abi.load().mi355x_rms_norm_dynamic_per_token_quant_slabs(
+        _ptr(out), _ptr(slabs), int(sk), _ptr(a_scales), a_scales.numel(), _ptr(b_scales), b_scales.numel(),
+        _ptr(weight), _ptr(scales), float(epsilon), _ptr(scale_ub), _ptr(residual), num_tokens, hidden,
+        _dt(weight), _stream())
+    _abi.check(rc, "rms_norm_dynamic_per_token_quant_slabs")
+
+
 # ------------------------------------------------------------------------- fp8 quant
 def _rows(t: torch.Tensor):
     hidden = t.size(-1)
@@ -543,6 +565,25 @@ def silu_and_mul_per_token_quant(input: torch.Tensor):
     if rc == 1:
         return None
     _abi.check(rc, "silu_and_mul_per_token_quant")
+    return out, scales
+
+
+def silu_and_mul_per_token_quant_slabs(slabs: torch.Tensor, sk: int, a_scales: torch.Tensor, b_scales: torch.Tensor,
+                                       num_tokens: int, d: int, dtype: torch.dtype):
+    """silu_and_mul_per_token_quant on the split-K slabs [sk, num_tokens, 2 d] (float32) of an fp8 gate_up GEMM
+    (scaled_mm_fp8_deferred) whose output type would have been `dtype`: bit-identical to the GEMM's finish launch
+    followed by that op.  None when not applicable."""
+    _dev(slabs, a_scales, b_scales)
+    if slabs.dtype != torch.float32 or slabs.numel() < sk * num_tokens * 2 * d or sk <= 0:
+        raise RuntimeError("silu_and_mul_per_token_quant_slabs: slabs must be float32 [sk, tokens, 2 d]")
+    out = torch.empty((num_tokens, d), dtype=torch.float8_e4m3fn, device=slabs.device)
+    scales = torch.empty((num_tokens, 1), dtype=torch.float32, device=slabs.device)
+    rc = _abi.load().mi355x_silu_and_mul_per_token_quant_slabs(
+        _ptr(out), _ptr(scales), _ptr(slabs), int(sk), _ptr(a_scales), a_scales.numel(), _ptr(b_scales),
+        b_scales.numel(), num_tokens, d, _DT[dtype], _stream())
+    if rc == 1:
+        return None
+    _abi.check(rc, "silu_and_mul_per_token_quant_slabs")
     return out, scales
 
 
@@ -829,7 +870,8 @@ def paged_attention_fused_qkv(out: torch.Tensor, exp_sums: Optional[torch.Tensor
                               slot_mapping: torch.Tensor, key_cache: torch.Tensor, value_cache: torch.Tensor,
                               num_heads: int, num_kv_heads: int, scale: float, block_tables: torch.Tensor,
                               seq_lens: torch.Tensor, block_size: int, max_seq_len: int,
-                              partitioned: bool, partition_size: int = PARTITION_SIZE) -> bool:
+                              partitioned: bool, partition_size: int = PARTITION_SIZE,
+                              slab_scales=None, quant_out=None) -> bool:
     """MI355X-side decode fusion: qkv_rope_cache folded into the paged-attention launch that follows it
     (include/mi355x_hotpath.h).  Returns False when the fused form does not apply to these shapes — the
     caller then runs qkv_rope_cache + paged_attention_v1 / _v2.  `out` [n, H, D]; the qkv buffer is not updated."""
@@ -853,6 +895,32 @@ def paged_attention_fused_qkv(out: torch.Tensor, exp_sums: Optional[torch.Tensor
             raise RuntimeError("paged_attention_fused_qkv: slabs must be float32 [sk, tokens, width]")
     if partitioned:
         _dev(exp_sums, max_logits, tmp_out)
+    if slab_scales is not None or quant_out is not None:
+        # fp8 model (mi355x_paged_attention_fused_qkv_w8): `slab_scales` = (a_scales [n] or [1], b_scales [width] or
+        # [1]) of the fp8 qkv GEMM whose slabs these are; `quant_out` = (fp8 [n, num_heads * head_size], float [n, 1]):
+        # the reduce launch of the partitioned form quantises the attention output per token, `out` stays unwritten
+        a_s, b_s = slab_scales if slab_scales is not None else (None, None)
+        q8, qs = quant_out if quant_out is not None else (None, None)
+        _dev(a_s, b_s, q8, qs)
+        if quant_out is not None and (q8.dtype != torch.float8_e4m3fn or qs.dtype != torch.float32
+                                      or q8.numel() != n * num_heads * head_size or qs.numel() != n
+                                      or not q8.is_contiguous()):
+            raise RuntimeError("paged_attention_fused_qkv: quant_out = (float8_e4m3fn [n, heads * d], float32 [n, 1])")
+        if slab_scales is not None and (a_s.dtype != torch.float32 or b_s.dtype != torch.float32
+                                        or not (a_s.is_contiguous() and b_s.is_contiguous())):
+            raise RuntimeError("paged_attention_fused_qkv: slab scales must be contiguous float32")
+        rc = _abi.load().mi355x_paged_attention_fused_qkv_w8(
+            _ptr(out), _ptr(exp_sums) if partitioned else None, _ptr(max_logits) if partitioned else None,
+            _ptr(tmp_out) if partitioned else None, _ptr(qkv), qkv.stride(0), _ptr(slabs) if sk > 0 else None,
+            int(sk), _ptr(positions), _ptr(cos_sin_cache), _ptr(slot_mapping), _ptr(key_cache), _ptr(value_cache),
+            n, num_heads, num_kv_heads, head_size, block_size, key_cache.size(4), float(scale), _ptr(block_tables),
+            _ptr(seq_lens), block_tables.stride(0), max_seq_len, key_cache.stride(0), key_cache.stride(1),
+            int(partition_size) if partitioned else 0, _dt(qkv), _ptr(a_s), a_s.numel() if a_s is not None else 0,
+            _ptr(b_s), b_s.numel() if b_s is not None else 0, _ptr(q8), _ptr(qs), _stream())
+        if rc == 1:
+            return False
+        _abi.check(rc, "paged_attention_fused_qkv_w8")
+        return True
     rc = _abi.load().mi355x_paged_attention_fused_qkv(
         _ptr(out), _ptr(exp_sums) if partitioned else None, _ptr(max_logits) if partitioned else None,
         _ptr(tmp_out) if partitioned else None, _ptr(qkv), qkv.stride(0), _ptr(slabs) if sk > 0 else None,
@@ -1125,6 +1193,36 @@ _F32_SCRATCH = {}
 def _scratch_f32(elems: int, device) -> torch.Tensor:
     """Per-device reusable fp32 scratch (stream-ordered use), grown on demand."""
     return _grow(_F32_SCRATCH, device, elems, torch.float32)
+
+
+def scaled_mm_fp8_deferred(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor, a_scales: torch.Tensor,
+                           b_scales: torch.Tensor, workspace: torch.Tensor) -> int:
+    """MI355X-side decode fusion: cutlass_scaled_mm (fp8, no bias) that may leave its K split as float32 partial slabs
+    `workspace[:sk * m * n]` ([sk, m, n]) for the consumer — returns sk (> 1), or 0 when `out` is final.  The
+    consumers (paged_attention_fused_qkv slab_scales=, silu_and_mul_per_token_quant_slabs,
+    rms_norm_dynamic_per_token_quant_slabs) produce the bits the GEMM's own finish launch would have stored."""
+    _dev(out, a, b, a_scales, b_scales, workspace)
+    if a.dim() != 2 or b.dim() != 2 or out.dim() != 2 or out.size(0) != a.size(0) or a.size(1) != b.size(0) \
+            or b.size(1) != out.size(1):
+        raise RuntimeError("scaled_mm_fp8_deferred: shape mismatch")
+    if a.stride(1) != 1 or out.stride(1) != 1 or b.stride(0) != 1:
+        raise RuntimeError("scaled_mm_fp8_deferred: a / out row-major, b column-major")
+    if a.dtype != torch.float8_e4m3fn or b.dtype != torch.float8_e4m3fn:
+        raise RuntimeError("scaled_mm_fp8_deferred: a and b must be float8_e4m3fn")
+    m, k = a.shape
+    n = b.size(1)
+    if a_scales.numel() not in (1, m) or b_scales.numel() not in (1, n) or a_scales.dtype != torch.float32 \
+            or b_scales.dtype != torch.float32 or not (a_scales.is_contiguous() and b_scales.is_contiguous()):
+        raise RuntimeError("scaled_mm_fp8_deferred: float32 contiguous scales, per-tensor or per-row / per-column")
+    if workspace.dtype != torch.float32:
+        raise RuntimeError("scaled_mm_fp8_deferred: workspace must be float32")
+    sk = ctypes.c_int(0)
+    rc = _abi.load().mi355x_scaled_mm_fp8_deferred(
+        _ptr(out), _ptr(a), _ptr(b), _ptr(a_scales), a_scales.numel(), _ptr(b_scales), b_scales.numel(),
+        _ptr(workspace), workspace.numel(), m, n, k, a.stride(0), b.stride(1), out.stride(0), _dt(out),
+        ctypes.byref(sk), _stream())
+    _abi.check(rc, "scaled_mm_fp8_deferred")
+    return sk.value
 
 
 def cutlass_scaled_mm_supports_fp8(cuda_device_capability: int) -> bool:

@@ -252,7 +252,7 @@ def decode_attention_fused(out: torch.Tensor, exp_sums: torch.Tensor, max_logits
                            key_cache: torch.Tensor, value_cache: torch.Tensor, num_heads: int, num_kv_heads: int,
                            scale: float, block_table: torch.Tensor, seq_lens: torch.Tensor, block_size: int,
                            max_seq_len: int, use_v1: Optional[bool] = None,
-                           partition_size: int = PARTITION_SIZE) -> bool:
+                           partition_size: int = PARTITION_SIZE, slab_scales=None, quant_out=None) -> bool:
     """qkv_rope_cache + decode_attention in one launch (MI355X-side fusion, include/mi355x_hotpath.h), with the
     same v1 / v2 choice as decode_attention.  False: not applicable to these shapes, nothing was launched."""
     head_size = key_cache.shape[2] * key_cache.shape[4]
@@ -262,7 +262,8 @@ def decode_attention_fused(out: torch.Tensor, exp_sums: torch.Tensor, max_logits
     return ops.paged_attention_fused_qkv(out, exp_sums, max_logits, tmp_out, qkv, slabs, sk, positions,
                                          cos_sin_cache, slot_mapping, key_cache, value_cache, num_heads,
                                          num_kv_heads, scale, block_table, seq_lens, block_size, max_seq_len,
-                                         not use_v1, partition_size)
+                                         not use_v1, partition_size, slab_scales=slab_scales,
+                                         quant_out=quant_out if not use_v1 else None)
 
 
 def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],

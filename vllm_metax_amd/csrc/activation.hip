@@ -67,9 +67,15 @@ __global__ void silu_and_mul_kernel(void* __restrict__ out_, const T* __restrict
 // per token, the T-rounded products stay in registers between the row maximum and the quantisation.  The bits of
 // silu_and_mul followed by dynamic_per_token_scaled_fp8_quant (csrc/activation_kernels.cu:14-36, csrc/quantization/
 // fp8/common.cu:91-133: s = max(absmax / 448, 1 / (448 * 512)), q = sat(float(x) / s)); no reference op of its own.
-template <typename T, int MAXC>
-__global__ __launch_bounds__(256) void silu_mul_per_token_quant_kernel(
-    uint8_t* __restrict__ out, float* __restrict__ scales, const T* __restrict__ in, int d) {
+// SLABS: the gate_up row is still the split-K partial slabs [sk][tokens][2 d] of an fp8 GEMM
+// (mi355x_scaled_mm_fp8_deferred): x = T(sum * a_scale[token] * b_scale[column]) = what its finish kernel stores.
+// NT threads per workgroup: 256, or 1024 for decode-sized batches (one workgroup per token: with 64 tokens only 64
+// CUs work, four times the loads in flight per CU then: 8B gate_up slabs 26.5 -> see profiles/r03 notes)
+template <typename T, int MAXC, bool SLABS = false, int NT = 256>
+__global__ __launch_bounds__(NT) void silu_mul_per_token_quant_kernel(
+    uint8_t* __restrict__ out, float* __restrict__ scales, const T* __restrict__ in, int d,
+    const float* __restrict__ slabs = nullptr, int sk = 0, int64_t slab_stride = 0,
+    SlabScales slab_scales = SlabScales{nullptr, nullptr, 0, 0}) {
   __shared__ float red[16];
   constexpr int V = 16 / sizeof(T);
   const int64_t token = blockIdx.x;
@@ -79,10 +85,17 @@ __global__ __launch_bounds__(256) void silu_mul_per_token_quant_kernel(
   float m = 0.f;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
-    const int i = (c * 256 + threadIdx.x) * V;
+    const int i = (c * NT + threadIdx.x) * V;
     if (i < d) {
-      const Vec16<T> xv = load16(x + i);
-      const Vec16<T> yv = load16(y + i);
+      Vec16<T> xv, yv;
+      if constexpr (SLABS) {
+        const float* sp = slabs + token * 2 * d;
+        slab_values<T, V>(sp + i, sk, slab_stride, slab_scales, token, i, xv.e);
+        slab_values<T, V>(sp + d + i, sk, slab_stride, slab_scales, token, d + i, yv.e);
+      } else {
+        xv = load16(x + i);
+        yv = load16(y + i);
+      }
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         act[c].e[j] = mul_t<T>(silu_t<T>(xv.e[j]), yv.e[j]);
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(256) void silu_mul_per_token_quant_kernel(
   uint8_t* o = out + token * d;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
-    const int i = (c * 256 + threadIdx.x) * V;
+    const int i = (c * NT + threadIdx.x) * V;
     if (i < d) {
       uint8_t q[V];
 #pragma unroll
@@ -172,6 +185,14 @@ extern "C" int mi355x_silu_and_mul_per_token_quant(void* out, float* scales, con
   return MI355X_DISPATCH_HALF(dtype, [&]() -> int {
     const scalar_t* in = static_cast<const scalar_t*>(input);
     uint8_t* o = static_cast<uint8_t*>(out);
+    if (num_tokens <= 128 && d > 2048) {   // decode: 1024 threads per token
+      const int chunks = (d / 8 + 1023) / 1024;
+      if (chunks <= 1)
+        hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 1, false, 1024>), dim3(num_tokens), dim3(1024), 0, s, o, scales, in, d);
+      else
+        hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 2, false, 1024>), dim3(num_tokens), dim3(1024), 0, s, o, scales, in, d);
+      return check_launch("silu_and_mul_per_token_quant");
+    }
     const int chunks = (d / 8 + 255) / 256;
     if (chunks <= 2)
       hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 2>), dim3(num_tokens), dim3(256), 0, s, o, scales, in, d);
@@ -180,5 +201,52 @@ extern "C" int mi355x_silu_and_mul_per_token_quant(void* out, float* scales, con
     else
       hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 8>), dim3(num_tokens), dim3(256), 0, s, o, scales, in, d);
     return check_launch("silu_and_mul_per_token_quant");
+  });
+}
+
+// The same with the gate_up row still in the split-K slabs of an fp8 GEMM (mi355x_scaled_mm_fp8_deferred);
+// bit-identical to the GEMM's finish launch followed by the op above.  Returns 1 when not applicable.
+extern "C" int mi355x_silu_and_mul_per_token_quant_slabs(void* out, float* scales, const float* slabs, int sk,
+                                                         const float* a_scales, int a_scales_numel,
+                                                         const float* b_scales, int b_scales_numel,
+                                                         int num_tokens, int d, int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && d > 0 && sk > 0, MI355X_EINVAL, "silu_and_mul_per_token_quant_slabs: bad sizes");
+  MI355X_REQUIRE(dtype == MI355X_F16 || dtype == MI355X_BF16, MI355X_EUNSUPPORTED,
+                 "silu_and_mul_per_token_quant_slabs: the GEMM's output type must be fp16 or bf16");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && scales && slabs && a_scales && b_scales, MI355X_EINVAL,
+                 "silu_and_mul_per_token_quant_slabs: null pointer");
+  MI355X_REQUIRE((a_scales_numel == 1 || a_scales_numel == num_tokens) &&
+                     (b_scales_numel == 1 || b_scales_numel == 2 * d),
+                 MI355X_EINVAL, "silu_and_mul_per_token_quant_slabs: scales per-tensor or per-token / per-column");
+  if (d % 8 != 0 || d > 16384 || (reinterpret_cast<uintptr_t>(slabs) & 15) || (reinterpret_cast<uintptr_t>(out) & 7))
+    return 1;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const SlabScales sc{a_scales, b_scales, a_scales_numel > 1, b_scales_numel > 1};
+  const int64_t stride = (int64_t)num_tokens * 2 * d;
+  return MI355X_DISPATCH_HALF(dtype, [&]() -> int {
+    uint8_t* o = static_cast<uint8_t*>(out);
+    const scalar_t* none = nullptr;
+    if (num_tokens <= 128 && d > 2048) {   // decode: 1024 threads per token
+      const int chunks = (d / 8 + 1023) / 1024;
+      if (chunks <= 1)
+        hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 1, true, 1024>), dim3(num_tokens), dim3(1024), 0,
+                           s, o, scales, none, d, slabs, sk, stride, sc);
+      else
+        hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 2, true, 1024>), dim3(num_tokens), dim3(1024), 0,
+                           s, o, scales, none, d, slabs, sk, stride, sc);
+      return check_launch("silu_and_mul_per_token_quant_slabs");
+    }
+    const int chunks = (d / 8 + 255) / 256;
+    if (chunks <= 2)
+      hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 2, true>), dim3(num_tokens), dim3(256), 0, s, o,
+                         scales, none, d, slabs, sk, stride, sc);
+    else if (chunks <= 4)
+      hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 4, true>), dim3(num_tokens), dim3(256), 0, s, o,
+                         scales, none, d, slabs, sk, stride, sc);
+    else
+      hipLaunchKernelGGL((silu_mul_per_token_quant_kernel<scalar_t, 8, true>), dim3(num_tokens), dim3(256), 0, s, o,
+                         scales, none, d, slabs, sk, stride, sc);
+    return check_launch("silu_and_mul_per_token_quant_slabs");
   });
 }

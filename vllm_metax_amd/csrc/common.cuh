@@ -267,6 +267,39 @@ __device__ __forceinline__ void sum_slabs(const float* __restrict__ sp, int sk, 
   }
 }
 
+// ---- split-K slabs of a W8A8 (fp8) GEMM ---------------------------------------------
+// A decode-sized scaled GEMM may leave its fp32 partial slabs unreduced (mi355x_scaled_mm_fp8_deferred); its
+// consumer then produces the value the GEMM's own finish kernel would have stored:
+//   T( (slab 0 + slab 1 + ...) * a_scale[row] * b_scale[col] + 0 )      (fp8_gemm.hip: OpFp8::finish, no bias)
+// `b == nullptr`: no scales — the w4a16 slabs (T(sum), mi355x_awq_gemm_deferred).
+struct SlabScales {
+  const float* a;   // activation scales: [rows] (a_per_row) or one value
+  const float* b;   // weight scales: [cols] (b_per_col) or one value; nullptr = unscaled slabs
+  int a_per_row, b_per_col;
+};
+__device__ __forceinline__ float scaled_finish_fp8(float acc, float as, float bs, float bi) {
+  float r = acc * as * bs + bi;
+  // materialised in fp32 (as the oracle's (acc * a_s * b_s + bias).to(dtype): two roundings): without the barrier
+  // hipcc folds the f16 cast of SOME call sites into v_fma_mixlo_f16 (one rounding) — the GEMM's own epilogue /
+  // finish kernel and the slab consumers of its deferred form must produce the same bits
+  asm volatile("" : "+v"(r));
+  return r;
+}
+// V consecutive columns col .. col + V - 1 of row `row` as T
+template <typename T, int V>
+__device__ __forceinline__ void slab_values(const float* __restrict__ sp, int sk, int64_t stride, const SlabScales& sc,
+                                            int64_t row, int col, T (&out)[V]) {
+  float acc[V];
+  sum_slabs<V>(sp, sk, stride, acc);
+  if (sc.b != nullptr) {
+    const float as = sc.a[sc.a_per_row ? row : 0];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = scaled_finish_fp8(acc[j], as, sc.b[sc.b_per_col ? col + j : 0], 0.f);
+  }
+#pragma unroll
+  for (int j = 0; j < V; ++j) out[j] = from_f32<T>(acc[j]);
+}
+
 // ---- dtype dispatch ------------------------------------------------------------
 #define MI355X_DISPATCH_FLOAT(dtype, ...)                                \
   [&]() -> int {                                                         \

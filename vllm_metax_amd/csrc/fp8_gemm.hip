@@ -67,7 +67,7 @@ struct OpFp8 {
   }
   // (a_s . A)(b_s . B) + bias, the order the fp8 oracle uses
   static __device__ __forceinline__ float finish(float acc, float as, float bs, float bi) {
-    return acc * as * bs + bi;
+    return scaled_finish_fp8(acc, as, bs, bi);   // (common.cuh: the slab consumers of the deferred form use it too)
   }
 };
 struct OpI8 {
@@ -112,6 +112,7 @@ struct Fp8Args {
   float* ws;
   int64_t ws_elems;
   hipStream_t stream;
+  int* defer_sk = nullptr;   // mi355x_scaled_mm_fp8_deferred: leave a K split's slabs to the consumer, report sk here
 };
 
 // ------------------------------------------------------------------------- large M
@@ -847,6 +848,10 @@ static int launch_decode(const Fp8Args& g, int a_per_row, int b_per_col, const D
                      b_per_col, static_cast<const T*>(g.bias), g.m, g.n, g.k, g.lda, g.ldb, g.ldc, p.steps);
   int rc = check_launch("scaled_mm(decode)");
   if (rc || p.sk == 1) return rc;
+  if (g.defer_sk != nullptr) {   // the consumer adds the slabs and applies the scales (common.cuh: slab_values)
+    *g.defer_sk = p.sk;
+    return MI355X_OK;
+  }
   if (g.n % 4 == 0 && g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(g.out) & 7) == 0 &&
       (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0) {
     hipLaunchKernelGGL((fp8_gemm_finish4_kernel<T, Op>), dim3((g.m * (g.n / 4) + 255) / 256), dim3(256), 0, g.stream,
@@ -1008,6 +1013,37 @@ extern "C" int mi355x_scaled_mm_fp8(void* out, const void* a, const void* b,
   Fp8Args g{out, static_cast<const uint8_t*>(a), static_cast<const uint8_t*>(b), a_scales,
             a_scales_numel, b_scales, b_scales_numel, bias, m, n, k, lda, ldb, ldc, workspace,
             workspace_elems, static_cast<hipStream_t>(stream)};
+  return MI355X_DISPATCH_HALF(out_dtype, [&] { return run_fp8<scalar_t, OpFp8>(g); });
+}
+
+// Decode-sized (m <= 64) fp8 GEMM whose K split, if the plan has one, is left as fp32 partial slabs
+// workspace[sk][m][n] for the consumer (*sk_out = sk; the consumer computes T(sum * a_s * b_s) = what this GEMM's
+// finish kernel stores — mi355x_paged_attention_fused_qkv_w8, mi355x_silu_and_mul_per_token_quant_slabs,
+// mi355x_rms_norm_dynamic_per_token_quant_slabs).  *sk_out = 0: `out` is final (no split, or a shape the streaming
+// kernel does not take).  No bias.
+extern "C" int mi355x_scaled_mm_fp8_deferred(void* out, const void* a, const void* b,
+                                             const float* a_scales, int a_scales_numel,
+                                             const float* b_scales, int b_scales_numel,
+                                             float* workspace, int64_t workspace_elems, int m, int n, int k,
+                                             int64_t lda, int64_t ldb, int64_t ldc, int out_dtype, int* sk_out,
+                                             mi355x_stream stream) {
+  MI355X_REQUIRE(sk_out != nullptr, MI355X_EINVAL, "scaled_mm_fp8_deferred: null sk_out");
+  *sk_out = 0;
+  MI355X_REQUIRE(m >= 0 && n > 0 && k > 0, MI355X_EINVAL, "scaled_mm_fp8_deferred: bad sizes");
+  MI355X_REQUIRE(k % 64 == 0, MI355X_EUNSUPPORTED, "scaled_mm_fp8_deferred: k = %d must be a multiple of 64", k);
+  MI355X_REQUIRE(lda % 16 == 0 && ldb % 16 == 0, MI355X_EUNSUPPORTED,
+                 "scaled_mm_fp8_deferred: lda / ldb must be multiples of 16 bytes");
+  MI355X_REQUIRE((a_scales_numel == 1 || a_scales_numel == m) && (b_scales_numel == 1 || b_scales_numel == n),
+                 MI355X_EINVAL, "scaled_mm_fp8_deferred: scales must be per-tensor or per-row / per-column");
+  if (m == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && a && b && a_scales && b_scales, MI355X_EINVAL, "scaled_mm_fp8_deferred: null pointer");
+  MI355X_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0,
+                 MI355X_EUNSUPPORTED, "scaled_mm_fp8_deferred: a and b must be 16-byte aligned");
+  Fp8Args g{out, static_cast<const uint8_t*>(a), static_cast<const uint8_t*>(b), a_scales,
+            a_scales_numel, b_scales, b_scales_numel, nullptr, m, n, k, lda, ldb, ldc, workspace,
+            workspace_elems, static_cast<hipStream_t>(stream)};
+  // slabs are consumed as 16-byte pieces of whole rows: n % 8 == 0, aligned scratch
+  if (m <= 64 && n % 8 == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) g.defer_sk = sk_out;
   return MI355X_DISPATCH_HALF(out_dtype, [&] { return run_fp8<scalar_t, OpFp8>(g); });
 }
 

@@ -28,7 +28,8 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
                                 int hidden_size,
                                 // optional: the input row is T(slab[0] + .. + slab[sk-1]) (fp32
                                 // split-K partials of the preceding GEMM, see mi355x_*_gemm_deferred)
-                                const float* __restrict__ slabs, int sk, int64_t slab_stride) {
+                                const float* __restrict__ slabs, int sk, int64_t slab_stride,
+                                SlabScales slab_scales = SlabScales{nullptr, nullptr, 0, 0}) {
   __shared__ float red[16];
   __shared__ float s_bcast;
   const int64_t row = blockIdx.x;
@@ -57,11 +58,9 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
       T iv[V];
       T rv[V];
       if (slabs != nullptr) {
-        // same arithmetic as w4a16_sum_slabs_kernel: fp32 sum in slab order, one rounding to T
-        float acc[V];
-        sum_slabs<V>(slabs + row * hidden_size + idx, sk, slab_stride, acc);
-#pragma unroll
-        for (int j = 0; j < V; ++j) iv[j] = from_f32<T>(acc[j]);
+        // same arithmetic as w4a16_sum_slabs_kernel: fp32 sum in slab order, one rounding to T (fp8 GEMM slabs:
+        // times the GEMM's scales first = its finish kernel, common.cuh)
+        slab_values<T, V>(slabs + row * hidden_size + idx, sk, slab_stride, slab_scales, row, idx, iv);
         if (res_row) {
           if constexpr (V > 1) *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(res_row + idx);
           else rv[0] = res_row[idx];
@@ -172,7 +171,7 @@ static int launch_norm(void* out, T* input, int64_t input_stride, T* residual,
                        const T* weight, const float* scale_in, float* scales_out,
                        const float* scale_ub, float eps, int num_tokens, int hidden,
                        hipStream_t s, const char* name, const float* slabs = nullptr, int sk = 0,
-                       int64_t slab_stride = 0) {
+                       int64_t slab_stride = 0, SlabScales slab_scales = SlabScales{nullptr, nullptr, 0, 0}) {
   constexpr int V = 16 / sizeof(T);
   const bool vec = (hidden % V == 0) && (input_stride % V == 0) && al16(input) &&
                    al16(weight) && (!residual || al16(residual)) &&
@@ -196,7 +195,7 @@ static int launch_norm(void* out, T* input, int64_t input_stride, T* residual,
 #define LAUNCH_NORM(VV, CC)                                                              \
   hipLaunchKernelGGL((rms_norm_kernel<T, VV, CC, FUSED_ADD, OUT>), grid, block, 0, s, out, \
                      input, input_stride, residual, weight, scale_in, scales_out,         \
-                     scale_ub, eps, hidden, slabs, sk, slab_stride)
+                     scale_ub, eps, hidden, slabs, sk, slab_stride, slab_scales)
   if (vec) {
     if (c <= 1) LAUNCH_NORM(V, 1);
     else if (c <= 2) LAUNCH_NORM(V, 2);
@@ -453,6 +452,36 @@ int mi355x_rms_norm_dynamic_per_token_quant(void* out, const void* input,
         static_cast<scalar_t*>(residual), static_cast<const scalar_t*>(weight), nullptr, scales,
         scale_ub, epsilon, num_tokens, hidden_size, static_cast<hipStream_t>(stream),
         "rms_norm_dynamic_per_token_quant");
+  });
+}
+
+/* rms_norm_dynamic_per_token_quant whose input rows are still the split-K partial slabs of an fp8 GEMM
+ * (mi355x_scaled_mm_fp8_deferred): input = T(sum of slabs * a_scale[token] * b_scale[column]), then the op above —
+ * bit-identical to the GEMM's finish launch followed by it.  `residual` as above (updated in place). */
+int mi355x_rms_norm_dynamic_per_token_quant_slabs(void* out, const float* slabs, int sk,
+                                                  const float* a_scales, int a_scales_numel,
+                                                  const float* b_scales, int b_scales_numel,
+                                                  const void* weight, float* scales, float epsilon,
+                                                  const float* scale_ub, void* residual, int num_tokens,
+                                                  int hidden_size, int dtype, mi355x_stream stream) {
+  MI355X_REQUIRE(num_tokens >= 0 && hidden_size > 0 && sk > 0, MI355X_EINVAL,
+                 "rms_norm_dynamic_per_token_quant_slabs: bad sizes");
+  if (num_tokens == 0) return MI355X_OK;
+  MI355X_REQUIRE(out && slabs && weight && scales && a_scales && b_scales, MI355X_EINVAL,
+                 "rms_norm_dynamic_per_token_quant_slabs: null pointer");
+  MI355X_REQUIRE((reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && hidden_size % 8 == 0, MI355X_EINVAL,
+                 "rms_norm_dynamic_per_token_quant_slabs: slabs must be 16-byte aligned, hidden %% 8 == 0");
+  MI355X_REQUIRE((a_scales_numel == 1 || a_scales_numel == num_tokens) &&
+                     (b_scales_numel == 1 || b_scales_numel == hidden_size),
+                 MI355X_EINVAL, "rms_norm_dynamic_per_token_quant_slabs: scales per-tensor or per-token / per-column");
+  return MI355X_DISPATCH_HALF(dtype, [&] {
+    // `input` is only an address for the vector-path checks here: every row comes from the slabs
+    return launch_norm<scalar_t, false, kOutFp8Dynamic>(
+        out, static_cast<scalar_t*>(const_cast<void*>(static_cast<const void*>(slabs))), hidden_size,
+        static_cast<scalar_t*>(residual), static_cast<const scalar_t*>(weight), nullptr, scales,
+        scale_ub, epsilon, num_tokens, hidden_size, static_cast<hipStream_t>(stream),
+        "rms_norm_dynamic_per_token_quant_slabs", slabs, sk, (int64_t)num_tokens * hidden_size,
+        SlabScales{a_scales, b_scales, a_scales_numel > 1, b_scales_numel > 1});
   });
 }
 

@@ -206,6 +206,7 @@ struct FusedQkv {
   const int64_t* positions;   // [num_seqs]
   const void* cos_sin_cache;  // [max_pos, head_size] scalar_t
   const int64_t* slot_mapping;  // [num_seqs]
+  SlabScales scales;            // fp8 qkv GEMM: the slabs still want a_scale[token] * b_scale[column] (common.cuh)
 };
 
 // HS == 0: head size is a run-time value (any multiple of 16/sizeof(T) up to 256).
@@ -325,10 +326,7 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
       const int col = (hs < GT ? head0 + hs : (hs == GT ? num_heads + kv_head : num_heads + num_kv_heads + kv_head)) * D + c * XT;
       Vec16<T> v;
       if (fq.sk > 0) {
-        float acc[XT];
-        sum_slabs<XT>(fq.slabs + (int64_t)seq * width + col, fq.sk, fq.slab_stride, acc);
-#pragma unroll
-        for (int j = 0; j < XT; ++j) v.e[j] = from_f32<T>(acc[j]);
+        slab_values<T, XT>(fq.slabs + (int64_t)seq * width + col, fq.sk, fq.slab_stride, fq.scales, seq, col, v.e);
       } else {
         v = load16(static_cast<const T*>(fq.qkv) + (int64_t)seq * fq.qkv_stride + col);
       }
@@ -689,6 +687,69 @@ __global__ __launch_bounds__(128) void paged_attention_reduce_kernel(
   }
 }
 
+// v2 reduce + dynamic per-token fp8 quantisation of the attention output (the input of an fp8 o_proj) in one launch:
+// one workgroup per sequence, wave h replays paged_attention_reduce_kernel for head h (np <= 64 partitions: the
+// weights of a head live in one wave, the same wave_max / wave_sum butterflies; that kernel's block_reduce adds an
+// exact 0 from its second wave), then the row maximum over all heads and the bytes of
+// dynamic_per_token_scaled_fp8_quant (fp8_quant.hip: s = max(absmax / 448, 1 / (448 * 512)), q = sat(float(o) / s)).
+// Bit-identical to the two launches (tests/test_gpu_paged_attention.py).
+template <typename T>
+__global__ __launch_bounds__(1024) void paged_attention_reduce_quant_kernel(
+    uint8_t* __restrict__ out_q, float* __restrict__ out_scales, const float* __restrict__ exp_sums,
+    const float* __restrict__ max_logits, const T* __restrict__ tmp_out, const int* __restrict__ seq_lens,
+    int num_heads, int head_size, int max_num_partitions, int partition_size) {
+  __shared__ float red[16];
+  __shared__ float s_scale;
+  const int lane = threadIdx.x & 63;
+  const int head = threadIdx.x >> 6;          // blockDim.x == 64 * num_heads
+  const int seq = blockIdx.x;
+  const int seq_len = seq_lens[seq];
+  const int np = (seq_len + partition_size - 1) / partition_size;
+  const int64_t base = ((int64_t)seq * num_heads + head) * max_num_partitions;
+  const T* tmp = tmp_out + base * head_size;
+  constexpr int kMaxD = 4;                    // head_size <= 256: up to 4 elements per lane
+  T o[kMaxD];
+  float amax = 0.f;
+  float w = 0.f, inv = 1.f;
+  if (np > 1) {
+    float m = lane < np ? max_logits[base + lane] : -3.402823466e+38f;
+    m = wave_max(m);
+    w = lane < np ? exp_sums[base + lane] * expf(max_logits[base + lane] - m) : 0.f;
+    float sum = wave_sum(w);
+    sum = sum + 0.f;                          // (the second wave of paged_attention_reduce_kernel's block_reduce)
+    inv = __fdividef(1.0f, sum + 1e-6f);
+  }
+#pragma unroll
+  for (int c = 0; c < kMaxD; ++c) {
+    const int i = lane + 64 * c;
+    o[c] = from_f32<T>(0.f);
+    if (i < head_size) {
+      if (np == 1) {
+        o[c] = tmp[i];
+      } else {
+        float acc = 0.f;
+        for (int j = 0; j < np; ++j) acc += to_f32(tmp[(int64_t)j * head_size + i]) * __shfl(w, j, 64) * inv;
+        o[c] = from_f32<T>(acc);
+      }
+      amax = fmaxf(amax, fabsf(to_f32(o[c])));
+    }
+  }
+  amax = block_reduce<true>(amax, red);
+  if (threadIdx.x == 0) {
+    const float sc = fmaxf(amax / kFp8Max, kFp8MinScale);
+    out_scales[seq] = sc;
+    s_scale = sc;
+  }
+  __syncthreads();
+  const float sc = s_scale;
+  uint8_t* q = out_q + ((int64_t)seq * num_heads + head) * head_size;
+#pragma unroll
+  for (int c = 0; c < kMaxD; ++c) {
+    const int i = lane + 64 * c;
+    if (i < head_size) q[i] = f32_to_fp8_sat(to_f32(o[c]) / sc);
+  }
+}
+
 struct PaArgs {
   void* out;
   float* exp_sums;
@@ -864,16 +925,23 @@ extern "C" {
 
 // returns 1 (no error set) when the fused form does not apply to the shapes: the caller then runs
 // mi355x_qkv_rope_cache followed by mi355x_paged_attention_v1 / _v2
-int mi355x_paged_attention_fused_qkv(
+static int fused_qkv_impl(
     void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* qkv, int64_t qkv_stride,
     const float* slabs, int sk, const int64_t* positions, const void* cos_sin_cache,
     const int64_t* slot_mapping, void* key_cache, void* value_cache, int num_seqs, int num_heads,
     int num_kv_heads, int head_size, int block_size, int x, float scale, const int* block_tables,
     const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len, int64_t kv_block_stride,
-    int64_t kv_head_stride, int partition_size, int dtype, mi355x_stream stream) {
-  MI355X_REQUIRE(sk >= 0 && partition_size >= 0, MI355X_EINVAL, "paged_attention_fused_qkv: bad sizes");
+    int64_t kv_head_stride, int partition_size, int dtype, mi355x_stream stream,
+    const float* a_scales, int a_scales_numel, const float* b_scales, int b_scales_numel,
+    void* out_q, float* out_scales, const char* name) {
+  MI355X_REQUIRE(sk >= 0 && partition_size >= 0, MI355X_EINVAL, "%s: bad sizes", name);
   if (dtype != MI355X_BF16 && dtype != MI355X_F16) return 1;
   if (head_size != 128 || block_size != 16 || x != 8) return 1;
+  // quantised output: the reduce + quant kernel of the partitioned form (one wave per head, <= 64 partitions)
+  const bool quant = out_q != nullptr;
+  if (quant && (partition_size == 0 || num_heads > 16 ||
+                (max_seq_len + partition_size - 1) / partition_size > 64))
+    return 1;
   PaArgs a{};
   a.out = out; a.exp_sums = exp_sums; a.max_logits = max_logits; a.tmp_out = tmp_out;
   a.query = qkv;   // (unused by the fused kernel; non-null for validate_pa)
@@ -885,26 +953,40 @@ int mi355x_paged_attention_fused_qkv(
   a.alibi_slopes = nullptr; a.q_stride = qkv_stride;
   a.kv_block_stride = kv_block_stride; a.kv_head_stride = kv_head_stride;
   a.partition_size = partition_size; a.stream = static_cast<hipStream_t>(stream);
-  int rc = validate_pa(a, "paged_attention_fused_qkv");
+  if (quant) a.out = out_q;   // (validate_pa wants a non-null output)
+  int rc = validate_pa(a, name);
   if (rc != MI355X_OK || num_seqs == 0) return rc;
   MI355X_REQUIRE(positions && cos_sin_cache && slot_mapping && (sk == 0 || slabs), MI355X_EINVAL,
-                 "paged_attention_fused_qkv: null pointer");
+                 "%s: null pointer", name);
   MI355X_REQUIRE(partition_size == 0 || (exp_sums && max_logits && tmp_out), MI355X_EINVAL,
-                 "paged_attention_fused_qkv: the partitioned form needs exp_sums / max_logits / tmp_out");
+                 "%s: the partitioned form needs exp_sums / max_logits / tmp_out", name);
   MI355X_REQUIRE(partition_size % 16 == 0, MI355X_EINVAL,
-                 "paged_attention_fused_qkv: partition_size must be 0 or a multiple of the block size (16)");
+                 "%s: partition_size must be 0 or a multiple of the block size (16)", name);
   MI355X_REQUIRE(((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(slabs) |
                    reinterpret_cast<uintptr_t>(cos_sin_cache) | reinterpret_cast<uintptr_t>(key_cache)) & 15) == 0 &&
                      qkv_stride % 8 == 0,
-                 MI355X_EINVAL, "paged_attention_fused_qkv: 16-byte aligned qkv / slabs / cos_sin / cache");
-  FusedQkv f{qkv, qkv_stride, sk > 0 ? slabs : nullptr, sk,
-             (int64_t)num_seqs * (num_heads + 2 * num_kv_heads) * head_size, positions, cos_sin_cache, slot_mapping};
+                 MI355X_EINVAL, "%s: 16-byte aligned qkv / slabs / cos_sin / cache", name);
+  const int width = (num_heads + 2 * num_kv_heads) * head_size;
+  MI355X_REQUIRE(b_scales == nullptr ||
+                     (a_scales && sk > 0 && (a_scales_numel == 1 || a_scales_numel == num_seqs) &&
+                      (b_scales_numel == 1 || b_scales_numel == width)),
+                 MI355X_EINVAL, "%s: scales need slabs (sk > 0), per-tensor or per-token / per-column", name);
+  MI355X_REQUIRE(!quant || out_scales, MI355X_EINVAL, "%s: quantised output needs out_scales", name);
+  FusedQkv f{qkv, qkv_stride, sk > 0 ? slabs : nullptr, sk, (int64_t)num_seqs * width, positions, cos_sin_cache,
+             slot_mapping, SlabScales{a_scales, b_scales, a_scales_numel > 1, b_scales_numel > 1}};
   a.fused = &f;
   rc = dtype == MI355X_BF16 ? launch_pa<bf16_t>(a) : launch_pa<f16_t>(a);
   if (rc != MI355X_OK || partition_size == 0) return rc;
-  // partitioned: the same reduce as paged_attention_v2
+  // partitioned: the same reduce as paged_attention_v2 (or reduce + per-token fp8 quantisation)
   const int max_parts = (max_seq_len + partition_size - 1) / partition_size;
   return MI355X_DISPATCH_HALF(dtype, [&] {
+    if (quant) {
+      hipLaunchKernelGGL(paged_attention_reduce_quant_kernel<scalar_t>, dim3(num_seqs), dim3(64 * num_heads), 0,
+                         a.stream, static_cast<uint8_t*>(out_q), out_scales, exp_sums, max_logits,
+                         static_cast<const scalar_t*>(tmp_out), seq_lens, num_heads, head_size, max_parts,
+                         partition_size);
+      return check_launch("paged_attention_fused_qkv_reduce_quant");
+    }
     hipLaunchKernelGGL(paged_attention_reduce_kernel<scalar_t>, dim3(num_heads, num_seqs),
                        dim3(128), (size_t)(max_parts > 0 ? max_parts : 1) * sizeof(float), a.stream,
                        static_cast<scalar_t*>(out), exp_sums, max_logits,
@@ -912,6 +994,35 @@ int mi355x_paged_attention_fused_qkv(
                        partition_size);
     return check_launch("paged_attention_fused_qkv_reduce");
   });
+}
+
+int mi355x_paged_attention_fused_qkv(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* qkv, int64_t qkv_stride,
+    const float* slabs, int sk, const int64_t* positions, const void* cos_sin_cache,
+    const int64_t* slot_mapping, void* key_cache, void* value_cache, int num_seqs, int num_heads,
+    int num_kv_heads, int head_size, int block_size, int x, float scale, const int* block_tables,
+    const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len, int64_t kv_block_stride,
+    int64_t kv_head_stride, int partition_size, int dtype, mi355x_stream stream) {
+  return fused_qkv_impl(out, exp_sums, max_logits, tmp_out, qkv, qkv_stride, slabs, sk, positions, cos_sin_cache,
+                        slot_mapping, key_cache, value_cache, num_seqs, num_heads, num_kv_heads, head_size,
+                        block_size, x, scale, block_tables, seq_lens, max_num_blocks_per_seq, max_seq_len,
+                        kv_block_stride, kv_head_stride, partition_size, dtype, stream, nullptr, 0, nullptr, 0,
+                        nullptr, nullptr, "paged_attention_fused_qkv");
+}
+
+int mi355x_paged_attention_fused_qkv_w8(
+    void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* qkv, int64_t qkv_stride,
+    const float* slabs, int sk, const int64_t* positions, const void* cos_sin_cache,
+    const int64_t* slot_mapping, void* key_cache, void* value_cache, int num_seqs, int num_heads,
+    int num_kv_heads, int head_size, int block_size, int x, float scale, const int* block_tables,
+    const int* seq_lens, int max_num_blocks_per_seq, int max_seq_len, int64_t kv_block_stride,
+    int64_t kv_head_stride, int partition_size, int dtype, const float* a_scales, int a_scales_numel,
+    const float* b_scales, int b_scales_numel, void* out_q, float* out_scales, mi355x_stream stream) {
+  return fused_qkv_impl(out, exp_sums, max_logits, tmp_out, qkv, qkv_stride, slabs, sk, positions, cos_sin_cache,
+                        slot_mapping, key_cache, value_cache, num_seqs, num_heads, num_kv_heads, head_size,
+                        block_size, x, scale, block_tables, seq_lens, max_num_blocks_per_seq, max_seq_len,
+                        kv_block_stride, kv_head_stride, partition_size, dtype, stream, a_scales, a_scales_numel,
+                        b_scales, b_scales_numel, out_q, out_scales, "paged_attention_fused_qkv_w8");
 }
 
 int mi355x_paged_attention_v1_max_seq_len(int num_seqs, int num_heads, int num_kv_heads,

@@ -22,7 +22,8 @@ from typing import List, Optional
 import torch
 
 from . import _custom_ops as ops
-from .attention.backend import decode_attention, decode_attention_fused, decode_partition_size
+from .attention.backend import (decode_attention, decode_attention_fused, decode_partition_size,
+                                use_paged_attention_v1)
 
 
 @dataclasses.dataclass
@@ -215,15 +216,39 @@ class QLinear:
             return ops.awq_gemm_silu_mul(x, self.qweight, self.qzeros, self.scales)
         return None
 
-    def deferred(self, x: torch.Tensor):
-        """(out, slabs, sk): like __call__, but a decode-sized AWQ GEMM may leave its split-K
-        slabs unreduced for ops.fused_add_rms_norm_slabs (sk == 0: `out` is final)."""
+    # fp8 decode: leave a K split of the scaled GEMM to its consumer (mi355x_scaled_mm_fp8_deferred) instead of a
+    # finish launch per GEMM; "0": every GEMM finishes itself (A/B switch for the bench)
+    fp8_defer = os.environ.get("MI355X_FP8_DEFER", "1") != "0"
+    # ... also by the per-token consumers (silu + quant of gate_up, norm + quant of o / down at tp == 1): built, bit-
+    # identical, and measured SLOWER than the GEMM's own finish launch (one workgroup per token reads the fp32 slabs
+    # with 64 CUs; the finish kernel spreads them over the chip: gate_up 8B 40.4 vs 46.9 us, 70B rank 24.4 vs 25.8,
+    # o / down +-0.5 us, scripts/bench_fp8_consumers.py) -> off; "1" switches it on (tests do)
+    fp8_defer_rows = os.environ.get("MI355X_FP8_DEFER_ROWS", "0") != "0"
+
+    def deferred(self, x, allow_scaled: bool = False):
+        """(out, slabs, sk, scales): like __call__, but a decode-sized GEMM may leave its split-K slabs unreduced
+        for its consumer (sk == 0: `out` is final).  AWQ: scales is None, the consumer rounds the slab sum
+        (ops.fused_add_rms_norm_slabs, qkv_rope_cache, paged_attention_fused_qkv).  fp8 (`allow_scaled`: the
+        caller's consumer takes them): scales = (activation scales [m, 1], weight scales [1, n]) that the consumer
+        still has to apply — the bits of the GEMM's own finish launch."""
         m = x.shape[0]
         if self.quant == "awq" and m <= 64:
             ws = self._workspace(m, x.device)
             out, sk = ops.awq_gemm_deferred(x, self.qweight, self.qzeros, self.scales, ws)
-            return out, ws, sk
-        return self(x), None, 0
+            return out, ws, sk, None
+        if self.quant == "fp8" and m <= 64 and allow_scaled and self.fp8_defer:
+            if isinstance(x, QuantAct):
+                xq, xs, odt = x.data, x.scales, x.dtype
+            else:
+                xq = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+                xs = torch.empty(m, 1, dtype=torch.float32, device=x.device)
+                ops.dynamic_per_token_scaled_fp8_quant(xq, x, xs, None)
+                odt = x.dtype
+            out = torch.empty(m, self.n, dtype=odt, device=xq.device)
+            ws = self._workspace(m, xq.device)
+            sk = ops.scaled_mm_fp8_deferred(out, xq, self.weight, xs, self.w_scale, ws)
+            return out, ws, sk, ((xs, self.w_scale) if sk > 0 else None)
+        return self(x), None, 0, None
 
     def weight_bytes(self) -> int:
         if self.quant in ("awq", "gptq"):
@@ -341,29 +366,48 @@ class HotPathModel:
             torch.distributed.all_reduce(x, group=self.tp_group)
         return x
 
-    def _norm_quant(self, x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor) -> QuantAct:
+    def _norm_quant(self, x: torch.Tensor, residual: Optional[torch.Tensor], weight: torch.Tensor,
+                    pending=(None, 0, None)) -> QuantAct:
         """rms_norm (fused add when `residual` is given: it then receives x + residual) + dynamic per-token fp8
-        quantisation in one launch."""
+        quantisation in one launch.  `pending` = (slabs, sk, scales): x is still the unreduced output of an fp8
+        GEMM — the norm adds the slabs and applies the GEMM's scales on its way in."""
         q = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
         sc = torch.empty(x.shape[0], 1, dtype=torch.float32, device=x.device)
-        ops.rms_norm_dynamic_per_token_quant(q, x.contiguous(), weight, sc, self.cfg.eps, None, residual)
+        if pending[1] > 0:
+            ops.rms_norm_dynamic_per_token_quant_slabs(q, pending[0], pending[1], pending[2][0], pending[2][1], weight,
+                                                       sc, self.cfg.eps, None, residual)
+        else:
+            ops.rms_norm_dynamic_per_token_quant(q, x.contiguous(), weight, sc, self.cfg.eps, None, residual)
         return QuantAct(q, sc, x.dtype)
+
+    def _fused_qkv_geometry(self, L) -> bool:
+        """Shapes mi355x_paged_attention_fused_qkv takes (include/mi355x_hotpath.h): decided up front, because an
+        fp8 qkv GEMM may only leave its slabs unreduced when that launch will consume them."""
+        return self.cfg.head_dim == 128 and self.BLOCK == 16 and self.kv_dtype == "auto" \
+            and self.dtype in (torch.bfloat16, torch.float16) and L.q_heads // L.kv_heads in (4, 8) \
+            and L.q_heads % L.kv_heads == 0
 
     def _slots(self, seq_ids: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
         blk = self.block_tables[seq_ids.long(), (positions // self.BLOCK).long()].long()
         return blk * self.BLOCK + (positions % self.BLOCK)
 
     def _layer(self, i: int, x: torch.Tensor, residual: Optional[torch.Tensor],
-               positions: torch.Tensor, slots: torch.Tensor, attn_fn, pending=(None, 0),
+               positions: torch.Tensor, slots: torch.Tensor, attn_fn, pending=(None, 0, None),
                defer: bool = False, attn_fused_fn=None):
-        """`pending` = (slabs, sk) when x is still the unreduced output of the previous layer's
-        down_proj (tp == 1 decode): the fused norm adds the slabs itself."""
+        """`pending` = (slabs, sk, scales) when x is still the unreduced output of the previous layer's
+        down_proj (tp == 1 decode): the fused norm adds the slabs itself (scales: an fp8 GEMM's, see
+        QLinear.deferred)."""
         L = self.layers[i]
         cfg = self.cfg
+        if len(pending) == 2:
+            pending = (pending[0], pending[1], None)
         fuse = defer and self.cfg.tp == 1   # with tp > 1 the all-reduce sits between GEMM and norm
         use_img = (not defer) and self.norm_image and x.shape[0] >= 1024 and pending[1] == 0 \
             and L.qkv.image() is not None and L.gate_up.image() is not None
-        nq = cfg.quant == "fp8" and self.fuse_norm_quant and x.dtype != torch.float32 and pending[1] == 0
+        nq = cfg.quant == "fp8" and self.fuse_norm_quant and x.dtype != torch.float32 \
+            and (pending[1] == 0 or pending[2] is not None)
+        # fp8 decode: the K splits of the qkv / gate_up (and at tp == 1 o / down) GEMMs are reduced by their consumers
+        w8_defer = defer and nq and QLinear.fp8_defer and hasattr(ops, "scaled_mm_fp8_deferred")
         if residual is None:
             residual = x.clone()
             h = ops.rms_norm_image(x, L.ln1, cfg.eps) if use_img else None
@@ -375,7 +419,7 @@ class HotPathModel:
         else:
             h = ops.fused_add_rms_norm_image(x, residual, L.ln1, cfg.eps) if use_img else None
             if h is None and nq:
-                h = self._norm_quant(x, residual, L.ln1)
+                h = self._norm_quant(x, residual, L.ln1, pending)
             if h is None:
                 ops.fused_add_rms_norm_slabs(x, residual, L.ln1, pending[0], pending[1], cfg.eps)
                 h = x
@@ -383,9 +427,12 @@ class HotPathModel:
         if defer and x.dtype != torch.float32 and self.kv_dtype == "auto":
             # decode: slab sum + rotary + cache write in one launch (column-parallel GEMM: no
             # collective between it and the rotary, so the fusion also holds under tp)
-            qkv, slabs, sk = L.qkv.deferred(h)
-            attn = attn_fused_fn(i, qkv, slabs, sk) if attn_fused_fn is not None else None
+            fq_w8 = w8_defer and attn_fused_fn is not None and self._fused_qkv_geometry(L)
+            qkv, slabs, sk, scl = L.qkv.deferred(h, allow_scaled=fq_w8)
+            attn = attn_fused_fn(i, qkv, slabs, sk, scl, fq_w8) if attn_fused_fn is not None else None
             if attn is None:
+                if scl is not None:
+                    raise RuntimeError("fp8 qkv slabs left without a consumer (paged_attention_fused_qkv refused)")
                 ops.qkv_rope_cache(qkv, slabs, sk, positions, self.cos_sin, self.k_cache[i],
                                    self.v_cache[i], slots, L.q_heads, L.kv_heads, cfg.head_dim)
             q = qkv[:, :L.q_size]
@@ -418,10 +465,15 @@ class HotPathModel:
         if attn is None:
             attn = attn_fn(i, q.view(-1, L.q_heads, cfg.head_dim))
         if fuse and not nq:
-            o, slabs, sk = L.o.deferred(attn.view(-1, L.q_size))
+            o, slabs, sk, _ = L.o.deferred(attn.view(-1, L.q_size))
             ops.fused_add_rms_norm_slabs(o, residual, L.ln2, slabs, sk, cfg.eps)
+        elif fuse and w8_defer and QLinear.fp8_defer_rows:
+            o, slabs, sk, scl = L.o.deferred(attn if isinstance(attn, QuantAct) else attn.view(-1, L.q_size),
+                                             allow_scaled=True)
+            o = self._norm_quant(o, residual, L.ln2, (slabs, sk, scl))
         else:
-            o = self._all_reduce(L.o(attn if isinstance(attn, ops.PackedOperand) else attn.view(-1, L.q_size)))
+            o = self._all_reduce(L.o(attn if isinstance(attn, (ops.PackedOperand, QuantAct))
+                                     else attn.view(-1, L.q_size)))
             o_img = ops.fused_add_rms_norm_image(o, residual, L.ln2, cfg.eps) if use_img else None
             if o_img is not None:
                 o = o_img
@@ -431,24 +483,32 @@ class HotPathModel:
                 ops.fused_add_rms_norm(o, residual, L.ln2, cfg.eps)
         act = L.gate_up.silu_mul(o)            # prefill-sized AWQ: fused into the GEMM epilogue
         if act is None:
-            gu = L.gate_up(o)
+            # (fp8 decode: the K split of gate_up is reduced by the silu + quant launch)
+            gu, slabs, sk, scl = L.gate_up.deferred(o, allow_scaled=L.ffn % 8 == 0 and L.ffn <= 16384) \
+                if w8_defer and QLinear.fp8_defer_rows else (L.gate_up(o), None, 0, None)
             if nq:                             # fp8: silu_and_mul + per-token quant of down_proj's input in one launch
-                qa = ops.silu_and_mul_per_token_quant(gu)
+                if scl is not None:
+                    qa = ops.silu_and_mul_per_token_quant_slabs(slabs, sk, scl[0], scl[1], gu.shape[0], L.ffn, gu.dtype)
+                    if qa is None:
+                        raise RuntimeError("fp8 gate_up slabs left without a consumer")
+                else:
+                    qa = ops.silu_and_mul_per_token_quant(gu)
                 if qa is not None:
                     act = QuantAct(qa[0], qa[1], gu.dtype)
         if act is None:
             act = torch.empty(gu.shape[0], L.ffn, dtype=gu.dtype, device=gu.device)
             ops.silu_and_mul(act, gu)
-        if fuse:
-            out, slabs, sk = L.down.deferred(act)
-            return out, residual, (slabs, sk)
+        if fuse and (cfg.quant != "fp8" or (w8_defer and QLinear.fp8_defer_rows and i + 1 < cfg.layers)):
+            # (fp8: the next layer's norm + quant applies the scales; the last layer finishes itself for _logits)
+            out, slabs, sk, scl = L.down.deferred(act, allow_scaled=True)
+            return out, residual, (slabs, sk, scl)
         out = self._all_reduce(L.down(act))
-        return out, residual, (None, 0)
+        return out, residual, (None, 0, None)
 
-    def _logits_argmax(self, x: torch.Tensor, residual: torch.Tensor, pending=(None, 0)) -> torch.Tensor:
+    def _logits_argmax(self, x: torch.Tensor, residual: torch.Tensor, pending=(None, 0, None)) -> torch.Tensor:
         return self._logits(x, residual, pending).argmax(dim=-1)
 
-    def _logits(self, x: torch.Tensor, residual: torch.Tensor, pending=(None, 0)) -> torch.Tensor:
+    def _logits(self, x: torch.Tensor, residual: torch.Tensor, pending=(None, 0, None)) -> torch.Tensor:
         ops.fused_add_rms_norm_slabs(x, residual, self.final_norm, pending[0], pending[1], self.cfg.eps)
         logits = torch.matmul(x, self.lm_head)
         if self._collectives():
@@ -523,6 +583,8 @@ class HotPathModel:
         # leaves CUs without a workgroup (a TP = 8 rank: 1 kv head) — attention/backend.py::decode_partition_size
         self.d_partition = decode_partition_size(num_seqs, H, self.layers[0].kv_heads, max_seq_len, self.BLOCK)
         P = (max_seq_len + self.d_partition - 1) // self.d_partition
+        self.d_use_v1 = use_paged_attention_v1(num_seqs, H, max_seq_len, self.layers[0].kv_heads, self.cfg.head_dim,
+                                               self.BLOCK, self.dtype) if self.device.type == "cuda" else True
         self.d_tmp = torch.empty(num_seqs, H, P, self.cfg.head_dim, dtype=self.dtype, device=dev)
         self.d_es = torch.empty(num_seqs, H, P, dtype=torch.float32, device=dev)
         self.d_ml = torch.empty_like(self.d_es)
@@ -547,16 +609,26 @@ class HotPathModel:
                              self.k_scale, self.v_scale, partition_size=self.d_partition)
             return out
 
-        def attn_fused_fn(i, qkv, slabs, sk):
+        def attn_fused_fn(i, qkv, slabs, sk, scl=None, w8=False):
             L = self.layers[i]
-            out = torch.empty(qkv.shape[0], L.q_heads, self.cfg.head_dim, dtype=qkv.dtype, device=qkv.device)
+            n = qkv.shape[0]
+            out = torch.empty(n, L.q_heads, self.cfg.head_dim, dtype=qkv.dtype, device=qkv.device)
+            # fp8 model, partitioned launch: its reduce kernel also quantises the output per token (o_proj's input)
+            quant = None
+            if w8 and not self.d_use_v1 and L.q_heads <= 16 \
+                    and -(-self.d_max_seq_len // self.d_partition) <= 64:
+                quant = (torch.empty(n, L.q_size, dtype=torch.float8_e4m3fn, device=qkv.device),
+                         torch.empty(n, 1, dtype=torch.float32, device=qkv.device))
             ok = decode_attention_fused(out, self.d_es, self.d_ml, self.d_tmp, qkv, slabs, sk, self.d_positions,
                                         self.cos_sin, slots, self.k_cache[i], self.v_cache[i], L.q_heads,
                                         L.kv_heads, self.scale, self.d_bt, self.d_seq_lens, self.BLOCK,
-                                        self.d_max_seq_len, partition_size=self.d_partition)
-            return out if ok else None
+                                        self.d_max_seq_len, use_v1=self.d_use_v1, partition_size=self.d_partition,
+                                        slab_scales=scl, quant_out=quant)
+            if not ok:
+                return None
+            return QuantAct(quant[0], quant[1], qkv.dtype) if quant is not None else out
 
-        pending = (None, 0)
+        pending = (None, 0, None)
         for i in range(self.cfg.layers):
             x, residual, pending = self._layer(i, x, residual, self.d_positions, slots, attn_fn,
                                                pending, defer=True,
