@@ -7,13 +7,19 @@ test_cutlass_scaled_mm.py:68-100 (fp8 of scaled randn, per-tensor / per-token /
 per-channel scales, optional bias); tolerance: one output ulp + 2e-4 * max|ref| (the
 reference test uses rtol 5e-1 / atol 1.5e-1; north_star asks <= 1e-3 rel).
 
-Fraction of elements allowed to differ from the exactly rounded result: 12 %.  Measured on
-MI355X (tests/diag_fp8_accum.py, profiles/r01_fp8_accum.txt): v_mfma_f32_16x16x32_fp8_fp8 is
-exact on integer-valued operands but on random e4m3 operands 4.7 % (K=64) .. 6.5 % (K=4096) of
-fp16-rounded outputs differ by one ulp from the exactly rounded sum — the MFMA's internal
-32-term adder does not keep full fp32 alignment.  That is a property of the hardware unit,
-not of the accumulation order, so it cannot be tightened in software.
+Fraction of elements allowed to differ from the oracle at all: 9 % for fp16 outputs, 3 % for bf16 (round 3;
+12 % for both before).  Measured on MI355X per kernel path and K against the fp64-exact result
+(scripts/diag_fp8_frac.py, profiles/r03_fp8_frac.txt): both fp8 MFMAs (v_mfma_f32_16x16x32_fp8_fp8 and
+v_mfma_scale_f32_16x16x128_f8f6f4) are exact on integer-valued operands, but on random e4m3 operands 4.6 % (K = 64)
+.. 6.5 % (K = 14336) of fp16-rounded and 0.8 .. 1.2 % of bf16-rounded outputs differ by one ulp from the exactly
+rounded sum, the same on the decode, tile and packed-image kernels — the MFMA's internal multi-term adder does not
+keep full fp32 alignment.  That is a property of the hardware unit, not of the accumulation order, so software
+cannot remove it; the bounds leave room for the fp32 accumulation error of the oracle itself.
 """
+
+
+def _max_frac(dtype):
+    return 0.09 if dtype == torch.float16 else 0.03
 import pytest
 import torch
 
@@ -44,6 +50,8 @@ def _mk(m, n, k, per_token, per_channel, bias, out_dtype, seed=0):
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,n,k", [(1, 256, 128), (16, 128, 512), (33, 496, 1024), (64, 1280, 8192),
                                    (100, 256, 256), (512, 512, 512), (300, 1008, 1024),
+                                   # 64 < M <= 320: passes of 64 rows through the decode kernel (ragged tail, split K)
+                                   (65, 1280, 8192), (129, 512, 1024), (320, 4096, 4096), (321, 512, 512),
                                    # prefill kernel: {16x16x32, 16x16x128 MFMA} x {plain, interleaved B}
                                    (1030, 272, 320), (2048, 512, 1024), (1100, 320, 192),
                                    (1030, 272, 384)])
@@ -56,7 +64,7 @@ def test_scaled_mm_fp8(out_dtype, m, n, k, per_token, per_channel, bias):
     bd = b.t().contiguous().to(d).t()          # keep it column-major on the device
     out = torch.empty(m, n, dtype=out_dtype, device=d)
     ops().cutlass_scaled_mm(out, a.to(d), bd, a_s.to(d), b_s.to(d), bi.to(d) if bias else None)
-    assert_gemm_close(out, ref, f"scaled_mm_fp8 {m}x{n}x{k}", max_frac=0.12)
+    assert_gemm_close(out, ref, f"scaled_mm_fp8 {m}x{n}x{k}", max_frac=_max_frac(out_dtype))
 
 
 def test_scaled_mm_fp8_llama70b_tp8_shapes():
@@ -69,7 +77,7 @@ def test_scaled_mm_fp8_llama70b_tp8_shapes():
             bd = b.t().contiguous().to(d).t()
             out = torch.empty(m, n, dtype=torch.bfloat16, device=d)
             ops().cutlass_scaled_mm(out, a.to(d), bd, a_s.to(d), b_s.to(d), None)
-            assert_gemm_close(out, ref, f"70B shape {m}x{n}x{k}", max_frac=0.12)
+            assert_gemm_close(out, ref, f"70B shape {m}x{n}x{k}", max_frac=_max_frac(torch.bfloat16))
 
 
 def test_scaled_mm_fp8_errors():
@@ -129,7 +137,7 @@ def test_scaled_mm_llama8b_bench_shapes(kind, k, n, m):
     got = out[rows.to(d)].cpu()
     if kind == "fp8":
         ref = R.scaled_mm_fp8(a_c, b_c, as_c, b_s.cpu(), torch.bfloat16)
-        assert_gemm_close(got, ref, f"fp8 bench shape {m}x{n}x{k}", max_frac=0.12)
+        assert_gemm_close(got, ref, f"fp8 bench shape {m}x{n}x{k}", max_frac=_max_frac(torch.bfloat16))
     else:
         from tests.util import assert_bit_exact
         ref = R.scaled_mm_int8(a_c, b_c, as_c, b_s.cpu(), torch.bfloat16)
@@ -137,10 +145,8 @@ def test_scaled_mm_llama8b_bench_shapes(kind, k, n, m):
     # a second call on the same operands gives the same bits (workspace reuse, split-K atomics on zeroed scratch)
     out2 = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=d)
     ops().cutlass_scaled_mm(out2, a, b_nk.t(), a_s, b_s, None)
-    if kind == "int8" or m > 64:
-        assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "not reproducible"
-    else:   # fp8 decode split-K: fp32 atomics, order-dependent in the last bit
-        assert_gemm_close(out2.cpu(), out.cpu(), "fp8 split-K repeat", max_frac=0.12)
+    # (slabs added in slab order since round 3: no atomics, every path is bit-reproducible)
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16)), "not reproducible"
 
 
 # ------------------------------------------------------------------ round 3: K split reduced by the consumer

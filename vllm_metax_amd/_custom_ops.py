@@ -15,6 +15,7 @@ HIP library, or with CPU tensors, raises.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -1258,9 +1259,9 @@ def cutlass_scaled_mm(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
     if bias is not None and (bias.numel() != n or not bias.is_contiguous() or bias.dtype != out.dtype):
         raise RuntimeError("cutlass_scaled_mm: bad bias")
     # small-M (decode) shapes split K across up to 8 workgroups, one fp32 / int32 partial slab [m, n] each
-    if m <= 64:
-        ws = torch.empty((8, m, n), dtype=torch.float32, device=a.device)
-    elif m >= 1024 and k % 64 == 0:
+    if m <= 320:       # (64 < m <= 320: passes of 64 rows through the decode kernel, one pass's slabs at a time)
+        ws = torch.empty((8, min(m, 64), n), dtype=torch.float32, device=a.device)
+    elif m >= int(os.environ.get("MI355X_F8_PACKED_MIN_M", "321")) and k % 64 == 0:
         # prefill: scratch for the re-tiled operands, (roundup(m,16) + roundup(n,16)) * k bytes
         need = ((m + 15) // 16 * 16 + (n + 15) // 16 * 16) * k
         ws = _scratch_f32((need + 3) // 4, a.device)

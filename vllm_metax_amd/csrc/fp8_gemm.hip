@@ -890,7 +890,10 @@ static int run_fp8(const Fp8Args& g) {
     // prefill: both operands re-tiled into operand images, then the LDS-DMA ring kernel
     const int64_t m_pad = ((int64_t)g.m + 15) / 16 * 16, n_pad = ((int64_t)g.n + 15) / 16 * 16;
     const int64_t need = (m_pad + n_pad) * g.k;   // bytes
-    if (g.m >= 1024 && g.ws != nullptr && g.ws_elems * 4 >= need && g.k % 64 == 0 &&
+    // 320 < M < 1024 too since round 3 (was the direct-load tile kernel: Llama-3-8B layer at M = 384 / 512 / 768
+    // 660 / 672 / 772 -> 409 / 422 / 470 us, profiles/r03_scaled_mm_mid_m.txt); MI355X_F8_PACKED_MIN_M for A/B runs
+    static const int kPackedMinM = [] { const char* e = getenv("MI355X_F8_PACKED_MIN_M"); return e ? atoi(e) : 321; }();
+    if (g.m >= kPackedMinM && g.ws != nullptr && g.ws_elems * 4 >= need && g.k % 64 == 0 &&
         (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0) {
       bf16_t* pa = reinterpret_cast<bf16_t*>(g.ws);
       bf16_t* pb = pa + m_pad * g.k / 2;
@@ -942,6 +945,32 @@ static int run_fp8(const Fp8Args& g) {
       if (rc) return rc;
       return check_launch("scaled_mm(packed)");
     }
+  }
+  // 64 < M <= 320 (decode batches above 64 sequences, small chunked-prefill budgets): passes of 64 rows through the
+  // streaming decode kernel — the weights of the second and later passes come from L2 / MALL.  Llama-3-8B layer at
+  // M = 128 / 256: 607 / 617 us on the direct-load tile kernel below (16-48 workgroups for the narrow projections,
+  // profiles/r03_scaled_mm_mid_m.txt) against ~100 us per pass here.
+  if (g.m > 64 && g.m <= 320 && g.k % 128 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0 && g.ldc % 4 == 0 &&
+      !getenv("MI355X_F8_DECODE_OLD")) {
+    bool done = true;
+    for (int row0 = 0; row0 < g.m; row0 += 64) {
+      Fp8Args p = g;
+      p.m = g.m - row0 < 64 ? g.m - row0 : 64;
+      p.a = g.a + (int64_t)row0 * g.lda;
+      p.out = static_cast<T*>(g.out) + (int64_t)row0 * g.ldc;
+      if (a_per_row) {
+        p.a_scales = g.a_scales + row0;
+        p.a_scales_numel = p.m > 1 ? p.m : 2;   // (stays "per row" for a one-row tail)
+      }
+      p.defer_sk = nullptr;
+      const int rc = run_decode<T, Op>(p, a_per_row, b_per_col);
+      if (rc < 0) return rc;
+      if (rc == 1) {           // no plan for this shape: only possible before anything was launched
+        done = false;
+        break;
+      }
+    }
+    if (done) return MI355X_OK;
   }
   if (g.m > 64) {
     const int num_m_blocks = (g.m + kF8BM - 1) / kF8BM;

@@ -429,8 +429,9 @@ void cutlass_scaled_mm(Tensor& out, const Tensor& a, const Tensor& b, const Tens
   }
   Guard g(a);
   Tensor ws;  // small-M (decode) shapes split K across up to 8 workgroups, one 4-byte partial slab [m, n] each
-  if (m <= 64 && m > 0) ws = at::empty({8, m, n}, a.options().dtype(at::kFloat));
-  else if (m >= 1024 && k % 64 == 0)   // prefill: scratch for the re-tiled operands (bytes / 4)
+  // (64 < m <= 320: passes of 64 rows through the decode kernel; above: the packed-image kernel)
+  if (m <= 320 && m > 0) ws = at::empty({8, m < 64 ? m : 64, n}, a.options().dtype(at::kFloat));
+  else if (m > 320 && k % 64 == 0)   // scratch for the re-tiled operands (bytes / 4)
     ws = at::empty({(((m + 15) / 16 * 16 + (n + 15) / 16 * 16) * k + 3) / 4}, a.options().dtype(at::kFloat));
   auto fn = is_i8 ? mi355x_scaled_mm_int8 : mi355x_scaled_mm_fp8;   // scaled_mm_entry.cu:34-39 / new
   ok(fn(out.data_ptr(), a.data_ptr(), b.data_ptr(), a_scales.data_ptr<float>(), a_scales.numel(),
