@@ -577,9 +577,9 @@ def hbm_weights_gb(model) -> dict:
     for L in model.layers:
         for q in (L.qkv, L.o, L.gate_up, L.down):
             w += q.weight_bytes()
-            im = getattr(q, "_image", None)
-            if im is not None:
-                img += im.numel() * im.element_size()
+            for im in (getattr(q, "_image", None), getattr(q, "_w8_image", None)):
+                if im is not None and im is not False:
+                    img += im.numel() * im.element_size()
     other = (model.embed.numel() + model.lm_head.numel()) * model.embed.element_size()
     return {"quantized_weights": round(w / 1e9, 3), "prefill_weight_images": round(img / 1e9, 3),
             "embed_lm_head": round(other / 1e9, 3), "total": round((w + img + other) / 1e9, 3)}
@@ -844,7 +844,11 @@ def main():
                    "layers": cfg.layers,
                    "prefill_weight_image": ("bf16 operand image of the int4 weights, dequantised once at load "
                                             "(MI355X_PREPACK=1): the prefill GEMM multiplies bf16 x bf16, decode "
-                                            "streams the int4 words" if image_on else "none"),
+                                            "streams the int4 words" if image_on else
+                                            ("operand image of the 8-bit weights (re-tiled once at load, same bytes "
+                                             "again): the packed prefill GEMM reads it instead of re-tiling per call"
+                                             if quant in ("fp8", "int8") and harness.QLinear.prepack
+                                             and weights_gb["prefill_weight_images"] > 0 else "none")),
                    "hbm_weights_gb": weights_gb,
                    "outputs_finite": True,
                    "decode_graph": bool(graph_ok) and not args.no_graph,

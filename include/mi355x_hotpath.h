@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 5   /* 5: + paged_attention_v2_ps, scaled_mm_fp8_deferred and its slab consumers (additive); 4: + paged_prefill_attention_alibi, silu_and_mul_per_token_quant (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
+#define MI355X_ABI_VERSION 5   /* 5: + paged_attention_v2_ps, scaled_mm_fp8_deferred and its slab consumers, scaled_mm_prepack(ed) (additive); 4: + paged_prefill_attention_alibi, silu_and_mul_per_token_quant (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
                                 * 2 was BREAKING (kv_cache_dtype / k_scale / v_scale inserted before `stream` in reshape_and_cache*,
                                 * paged_attention_v1/_v2, paged_prefill_attention): a binding must refuse a library whose
                                 * mi355x_abi_version() differs from the version it was written for (vllm_metax_amd/_abi.py does) */
@@ -557,6 +557,18 @@ int mi355x_scaled_mm_fp8(void* out, const void* a, const void* b, const float* a
                          const void* bias, float* workspace, int64_t workspace_elems, int m,
                          int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype,
                          mi355x_stream stream);
+
+/* Load-time weight image of the 8-bit (fp8 / int8) GEMM's packed path (m > 320): mi355x_scaled_mm_* re-tile the
+ * weights into 1-KiB operand images on every call (n * k bytes read + written: ~90 us per Llama-3-8B layer);
+ * mi355x_scaled_mm_prepack does it once (image: n * k bytes; n % 64 == 0, k % 64 == 0, else returns 1) and
+ * mi355x_scaled_mm_prepacked multiplies by the image — bit-identical to the call on b.  workspace: >= roundup(m, 16)
+ * * k bytes (the activation image).  Decode-sized calls keep streaming b itself.  (No reference op: the reference's
+ * int8 path repacks nothing, cutlass reads b directly.) */
+int mi355x_scaled_mm_prepack(void* image, const void* b, int n, int k, int64_t ldb, mi355x_stream stream);
+int mi355x_scaled_mm_prepacked(void* out, const void* a, const void* b_image, const float* a_scales,
+                               int a_scales_numel, const float* b_scales, int b_scales_numel, const void* bias,
+                               float* workspace, int64_t workspace_elems, int m, int n, int k, int64_t lda,
+                               int64_t ldc, int out_dtype, int is_int8, mi355x_stream stream);
 
 /* ---- fp8 decode step: the K split of a scaled GEMM reduced by its consumer (round 3; no reference ops) --------
  * Decode-sized (m <= 64) W8A8 GEMMs are launch-latency-bound: every launch of the fp8 decoder layer

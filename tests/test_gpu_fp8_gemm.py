@@ -220,3 +220,36 @@ def test_norm_quant_on_slabs_is_bit_identical(dtype, with_residual):
     assert torch.equal(q1.view(torch.uint8), q2.view(torch.uint8))
     if with_residual:
         assert torch.equal(r1.view(torch.int16), r2.view(torch.int16))
+
+
+@pytest.mark.parametrize("kind", ["fp8", "int8"])
+@pytest.mark.parametrize("shape", [(384, 1280, 8192), (1030, 512, 320), (2048, 7168, 1024), (512, 4096, 4096)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_scaled_mm_prepacked_weight_image_is_bit_identical(kind, shape, bias):
+    """mi355x_scaled_mm_prepack + mi355x_scaled_mm_prepacked (load-time weight image of the packed 8-bit GEMM) against
+    cutlass_scaled_mm on the weights themselves: the same bits."""
+    m, n, k = shape
+    d = dev()
+    g = torch.Generator().manual_seed(m + n)
+    if kind == "fp8":
+        a = (torch.randn(m, k, generator=g) * 2).clamp(-448, 448).to(FP8).to(d)
+        b = (torch.randn(n, k, generator=g) * 2).clamp(-448, 448).to(FP8).to(d).t()
+    else:
+        a = torch.randint(-127, 128, (m, k), generator=g, dtype=torch.int32).to(torch.int8).to(d)
+        b = torch.randint(-127, 128, (n, k), generator=g, dtype=torch.int32).to(torch.int8).to(d).t()
+    a_s = (torch.rand(m, 1, generator=g) * 9e-3 + 1e-3).to(d)
+    b_s = (torch.rand(1, n, generator=g) * 9e-3 + 1e-3).to(d)
+    bi = (torch.rand(n, generator=g) * 2 - 1).to(torch.bfloat16).to(d) if bias else None
+    ref = torch.empty(m, n, dtype=torch.bfloat16, device=d)
+    ops().cutlass_scaled_mm(ref, a, b, a_s, b_s, bi)
+    img = ops().scaled_mm_prepack(b)
+    assert img is not None and img.numel() == n * k
+    out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=d)
+    ops().scaled_mm_prepacked(out, a, img, n, a_s, b_s, bi)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+
+
+def test_scaled_mm_prepack_not_applicable():
+    d = dev()
+    b = torch.zeros(1000, 128, dtype=torch.int8, device=d).t()      # n = 1000: not a multiple of 64
+    assert ops().scaled_mm_prepack(b) is None

@@ -102,6 +102,9 @@ PROTOTYPES = {
     "mi355x_dynamic_scaled_int8_quant": (_I, [_P, _P, _P, _I, _I, _L, _I, _P]),
     "mi355x_scaled_mm_fp8": (
         _I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _L, _I, _I, _I, _L, _L, _L, _I, _P]),
+    "mi355x_scaled_mm_prepack": (_I, [_P, _P, _I, _I, _L, _P]),
+    "mi355x_scaled_mm_prepacked": (
+        _I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _L, _I, _I, _I, _L, _L, _I, _I, _P]),
     "mi355x_scaled_mm_fp8_deferred": (
         _I, [_P, _P, _P, _P, _I, _P, _I, _P, _L, _I, _I, _I, _L, _L, _L, _I, _P, _P]),
     "mi355x_paged_attention_fused_qkv_w8": (

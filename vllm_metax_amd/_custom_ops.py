@@ -1196,6 +1196,43 @@ def _scratch_f32(elems: int, device) -> torch.Tensor:
     return _grow(_F32_SCRATCH, device, elems, torch.float32)
 
 
+def scaled_mm_prepack(b: torch.Tensor) -> Optional[torch.Tensor]:
+    """Load-time operand image of an fp8 / int8 weight `b` [k, n] (column-major, as cutlass_scaled_mm takes it) for
+    the packed path of the 8-bit GEMM (m > 320): uint8 [n * k], or None when the shape has none (n % 64, k % 64)."""
+    _dev(b)
+    if b.dim() != 2 or b.stride(0) != 1 or b.dtype not in (torch.float8_e4m3fn, torch.int8):
+        raise RuntimeError("scaled_mm_prepack: b must be column-major float8_e4m3fn or int8 [k, n]")
+    k, n = b.shape
+    image = torch.empty(n * k, dtype=torch.uint8, device=b.device)
+    rc = _abi.load().mi355x_scaled_mm_prepack(_ptr(image), _ptr(b), n, k, b.stride(1), _stream())
+    if rc == 1:
+        return None
+    _abi.check(rc, "scaled_mm_prepack")
+    return image
+
+
+def scaled_mm_prepacked(out: torch.Tensor, a: torch.Tensor, b_image: torch.Tensor, n: int, a_scales: torch.Tensor,
+                        b_scales: torch.Tensor, bias: Optional[torch.Tensor] = None) -> None:
+    """cutlass_scaled_mm(out, a, b, ...) with b given as scaled_mm_prepack(b) (m > 320): bit-identical, without the
+    per-call re-tiling of the weights."""
+    _dev(out, a, b_image, a_scales, b_scales, bias)
+    m, k = a.shape
+    if a.stride(1) != 1 or out.stride(1) != 1 or out.shape != (m, n) or b_image.numel() != n * k \
+            or a.dtype not in (torch.float8_e4m3fn, torch.int8):
+        raise RuntimeError("scaled_mm_prepacked: shape / layout mismatch")
+    if a_scales.numel() not in (1, m) or b_scales.numel() not in (1, n) or a_scales.dtype != torch.float32 \
+            or b_scales.dtype != torch.float32 or not (a_scales.is_contiguous() and b_scales.is_contiguous()):
+        raise RuntimeError("scaled_mm_prepacked: float32 contiguous scales, per-tensor or per-row / per-column")
+    if bias is not None and (bias.numel() != n or not bias.is_contiguous() or bias.dtype != out.dtype):
+        raise RuntimeError("scaled_mm_prepacked: bad bias")
+    ws = _scratch_f32(((m + 15) // 16 * 16 * k + 3) // 4, a.device)
+    rc = _abi.load().mi355x_scaled_mm_prepacked(
+        _ptr(out), _ptr(a), _ptr(b_image), _ptr(a_scales), a_scales.numel(), _ptr(b_scales), b_scales.numel(),
+        _ptr(bias), _ptr(ws), ws.numel(), m, n, k, a.stride(0), out.stride(0), _dt(out),
+        1 if a.dtype == torch.int8 else 0, _stream())
+    _abi.check(rc, "scaled_mm_prepacked")
+
+
 def scaled_mm_fp8_deferred(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor, a_scales: torch.Tensor,
                            b_scales: torch.Tensor, workspace: torch.Tensor) -> int:
     """MI355X-side decode fusion: cutlass_scaled_mm (fp8, no bias) that may leave its K split as float32 partial slabs

@@ -113,6 +113,8 @@ struct Fp8Args {
   int64_t ws_elems;
   hipStream_t stream;
   int* defer_sk = nullptr;   // mi355x_scaled_mm_fp8_deferred: leave a K split's slabs to the consumer, report sk here
+  const void* b_image = nullptr;   // mi355x_scaled_mm_prepack: the weights' operand image (rows interleaved by 4),
+                                   // built once at load time; `b` is then unused by the packed path
 };
 
 // ------------------------------------------------------------------------- large M
@@ -889,23 +891,25 @@ static int run_fp8(const Fp8Args& g) {
   {
     // prefill: both operands re-tiled into operand images, then the LDS-DMA ring kernel
     const int64_t m_pad = ((int64_t)g.m + 15) / 16 * 16, n_pad = ((int64_t)g.n + 15) / 16 * 16;
-    const int64_t need = (m_pad + n_pad) * g.k;   // bytes
+    const int64_t need = (m_pad + (g.b_image ? 0 : n_pad)) * g.k;   // bytes
     // 320 < M < 1024 too since round 3 (was the direct-load tile kernel: Llama-3-8B layer at M = 384 / 512 / 768
     // 660 / 672 / 772 -> 409 / 422 / 470 us, profiles/r03_scaled_mm_mid_m.txt); MI355X_F8_PACKED_MIN_M for A/B runs
     static const int kPackedMinM = [] { const char* e = getenv("MI355X_F8_PACKED_MIN_M"); return e ? atoi(e) : 321; }();
     if (g.m >= kPackedMinM && g.ws != nullptr && g.ws_elems * 4 >= need && g.k % 64 == 0 &&
         (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0) {
       bf16_t* pa = reinterpret_cast<bf16_t*>(g.ws);
-      bf16_t* pb = pa + m_pad * g.k / 2;
-      // 4 adjacent output columns per lane (8-byte stores) when the shape allows it
+      const bf16_t* pb = g.b_image ? static_cast<const bf16_t*>(g.b_image) : pa + m_pad * g.k / 2;
+      // 4 adjacent output columns per lane (8-byte stores) when the shape allows it (a prepacked image is always
+      // interleaved: its entry point checked the same conditions)
       const bool il = g.n % 64 == 0 && g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
       const int k2 = g.k / 2;   // the byte matrices viewed as 2-byte elements
       hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, (int)(m_pad / 16)),
                          dim3(256), 0, g.stream, pa, reinterpret_cast<const bf16_t*>(g.a), g.m, k2,
                          g.lda / 2);
-      hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, (int)(n_pad / 16)),
-                         dim3(256), 0, g.stream, pb, reinterpret_cast<const bf16_t*>(g.b), g.n, k2,
-                         g.ldb / 2, il ? 1 : 0);
+      if (!g.b_image)
+        hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, (int)(n_pad / 16)),
+                           dim3(256), 0, g.stream, pa + m_pad * g.k / 2, reinterpret_cast<const bf16_t*>(g.b), g.n, k2,
+                           g.ldb / 2, il ? 1 : 0);
       int rc = check_launch("scaled_mm(pack)");
       if (rc) return rc;
       const int num_m_blocks = (g.m + 255) / 256, num_n_blocks = (g.n + 255) / 256;
@@ -1042,6 +1046,51 @@ extern "C" int mi355x_scaled_mm_fp8(void* out, const void* a, const void* b,
   Fp8Args g{out, static_cast<const uint8_t*>(a), static_cast<const uint8_t*>(b), a_scales,
             a_scales_numel, b_scales, b_scales_numel, bias, m, n, k, lda, ldb, ldc, workspace,
             workspace_elems, static_cast<hipStream_t>(stream)};
+  return MI355X_DISPATCH_HALF(out_dtype, [&] { return run_fp8<scalar_t, OpFp8>(g); });
+}
+
+// Load-time weight image of the 8-bit GEMM's packed path (fp8 and int8 alike: bytes): what pack_a_kernel derives
+// from `b` on every call with m > 320, computed once — n * k bytes, rows interleaved by 4 (n % 64 == 0, k % 64 == 0).
+// Returns 1 when the shape has no such image (the caller keeps calling mi355x_scaled_mm_*).
+extern "C" int mi355x_scaled_mm_prepack(void* image, const void* b, int n, int k, int64_t ldb,
+                                        mi355x_stream stream) {
+  MI355X_REQUIRE(n > 0 && k > 0, MI355X_EINVAL, "scaled_mm_prepack: bad sizes");
+  MI355X_REQUIRE(image && b, MI355X_EINVAL, "scaled_mm_prepack: null pointer");
+  if (n % 64 != 0 || k % 64 != 0 || ldb % 16 != 0 ||
+      ((reinterpret_cast<uintptr_t>(image) | reinterpret_cast<uintptr_t>(b)) & 15) != 0)
+    return 1;
+  const int k2 = k / 2;
+  hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, n / 16), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<bf16_t*>(image),
+                     static_cast<const bf16_t*>(b), n, k2, ldb / 2, 1);
+  return check_launch("scaled_mm_prepack");
+}
+
+// cutlass_scaled_mm with the weights given as that image (m > 320, the packed path; workspace: >= roundup(m, 16) * k
+// bytes for the activation image).  is_int8: the int8 arithmetic of mi355x_scaled_mm_int8.  Bit-identical to the
+// call on `b` itself.
+extern "C" int mi355x_scaled_mm_prepacked(void* out, const void* a, const void* b_image,
+                                          const float* a_scales, int a_scales_numel,
+                                          const float* b_scales, int b_scales_numel, const void* bias,
+                                          float* workspace, int64_t workspace_elems, int m, int n, int k,
+                                          int64_t lda, int64_t ldc, int out_dtype, int is_int8,
+                                          mi355x_stream stream) {
+  MI355X_REQUIRE(m > 320 && n > 0 && k > 0 && n % 64 == 0 && k % 64 == 0, MI355X_EINVAL,
+                 "scaled_mm_prepacked: needs m > 320, n %% 64 == 0, k %% 64 == 0");
+  MI355X_REQUIRE(lda % 16 == 0 && ldc % 4 == 0, MI355X_EUNSUPPORTED, "scaled_mm_prepacked: lda %% 16, ldc %% 4");
+  MI355X_REQUIRE((a_scales_numel == 1 || a_scales_numel == m) && (b_scales_numel == 1 || b_scales_numel == n),
+                 MI355X_EINVAL, "scaled_mm_prepacked: scales must be per-tensor or per-row / per-column");
+  MI355X_REQUIRE(out && a && b_image && a_scales && b_scales && workspace, MI355X_EINVAL,
+                 "scaled_mm_prepacked: null pointer");
+  MI355X_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b_image) |
+                   reinterpret_cast<uintptr_t>(workspace)) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0,
+                 MI355X_EUNSUPPORTED, "scaled_mm_prepacked: alignment");
+  const int64_t m_pad = ((int64_t)m + 15) / 16 * 16;
+  MI355X_REQUIRE(workspace_elems * 4 >= m_pad * k, MI355X_EINVAL, "scaled_mm_prepacked: workspace too small");
+  Fp8Args g{out, static_cast<const uint8_t*>(a), nullptr, a_scales, a_scales_numel, b_scales, b_scales_numel, bias,
+            m, n, k, lda, 0, ldc, workspace, workspace_elems, static_cast<hipStream_t>(stream)};
+  g.b_image = b_image;
+  if (is_int8) return MI355X_DISPATCH_HALF(out_dtype, [&] { return run_fp8<scalar_t, OpI8>(g); });
   return MI355X_DISPATCH_HALF(out_dtype, [&] { return run_fp8<scalar_t, OpFp8>(g); });
 }
 

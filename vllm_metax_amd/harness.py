@@ -193,14 +193,27 @@ class QLinear:
                 ops.dynamic_per_token_scaled_fp8_quant(xq, x, xs, None)
                 odt = x.dtype
             out = torch.empty(m, self.n, dtype=odt, device=xq.device)
-            ops.cutlass_scaled_mm(out, xq, self.weight, xs, self.w_scale, None)
+            self._scaled_mm(out, xq, xs)
             return out
         if self.quant == "int8":
             xq, xs, _ = ops.scaled_int8_quant(x)
             out = torch.empty(m, self.n, dtype=x.dtype, device=x.device)
-            ops.cutlass_scaled_mm(out, xq, self.weight, xs, self.w_scale, None)
+            self._scaled_mm(out, xq, xs)
             return out
         return torch.matmul(x, self.weight)
+
+    def _scaled_mm(self, out, xq, xs):
+        """cutlass_scaled_mm on this layer's 8-bit weights; prefill-sized calls (m > 320) multiply by the weights'
+        operand image built once at first use (mi355x_scaled_mm_prepack: n * k more bytes per layer, the per-call
+        re-tiling of the weights gone) — MI355X_PREPACK=0 or a shape without an image: the plain op."""
+        if xq.shape[0] > 320 and self.prepack and hasattr(ops, "scaled_mm_prepack"):
+            if getattr(self, "_w8_image", None) is None:
+                img = ops.scaled_mm_prepack(self.weight)
+                self._w8_image = img if img is not None else False
+            if self._w8_image is not False:
+                ops.scaled_mm_prepacked(out, xq, self._w8_image, self.n, xs, self.w_scale, None)
+                return
+        ops.cutlass_scaled_mm(out, xq, self.weight, xs, self.w_scale, None)
 
     def silu_mul(self, x: torch.Tensor):
         """silu_and_mul(self(x)) in one launch where the library supports it (AWQ, M >= 1024), else None."""
