@@ -106,15 +106,16 @@ __global__ __launch_bounds__(NT) void silu_mul_per_token_quant_kernel(
   m = block_reduce<true>(m, red);
   const float s = fmaxf(m / kFp8Max, kFp8MinScale);
   if (threadIdx.x == 0) scales[token] = s;
+  const RowDiv rdiv = make_row_div(s);
   uint8_t* o = out + token * d;
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
     const int i = (c * NT + threadIdx.x) * V;
     if (i < d) {
-      uint8_t q[V];
+      float y[V];
 #pragma unroll
-      for (int j = 0; j < V; ++j) q[j] = f32_to_fp8_sat(to_f32(act[c].e[j]) / s);
-      *reinterpret_cast<uint2*>(o + i) = *reinterpret_cast<const uint2*>(q);
+      for (int j = 0; j < V; ++j) y[j] = row_div(to_f32(act[c].e[j]), rdiv);
+      *reinterpret_cast<uint2*>(o + i) = f32x8_to_fp8x8_sat(y);
     }
   }
 }

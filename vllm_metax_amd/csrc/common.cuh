@@ -222,6 +222,55 @@ __device__ __forceinline__ uint16_t f32x2_to_fp8x2_sat(float a, float b) {
   return static_cast<uint16_t>(packed & 0xffff);
 }
 
+// ---- x / s for a whole row with ONE divisor (dynamic per-token quantisation) ---------------------------------
+// The reference divides (fp8 = sat(float(x) / scale), csrc/quantization/fp8/common.cuh): an IEEE division is ~10
+// VALU operations per element and made the fused norm + quant kernels VALU-bound (profiles/r03 notes).  With the
+// correctly rounded reciprocal y = RN(1 / s) — one true division per row — Markstein's correction
+//   q0 = RN(x y);  r = x - s q0 (exact in an fma);  q = RN(q0 + r y)
+// gives the correctly rounded quotient RN(x / s), i.e. the bits of the division, in 3 operations (IBM J. R&D 34(1),
+// 1990, Thm 8; Cornea et al. 2002).  Outside the theorem — a divisor whose significand is all ones, non-finite x —
+// the division itself runs (row-uniform / practically never taken branches).  Quotients so small that r underflows
+// round to the fp8 zero of the same sign either way.
+struct RowDiv {
+  float s, y;
+  bool fast;
+};
+__device__ __forceinline__ RowDiv make_row_div(float s) {
+  RowDiv d;
+  d.s = s;
+  d.y = 1.0f / s;
+  d.fast = (__float_as_uint(s) & 0x7FFFFFu) != 0x7FFFFFu && s > 0.f && s < 3.0e38f;
+  return d;
+}
+__device__ __forceinline__ float row_div(float x, const RowDiv& d) {
+  if (!d.fast) return x / d.s;
+  float q0 = x * d.y;
+  asm volatile("" : "+v"(q0));                 // (the rounded product, in both uses: no contraction into the fmas)
+  const float r = __builtin_fmaf(-d.s, q0, x);
+  float q = __builtin_fmaf(r, d.y, q0);
+  if (!(fabsf(x) <= 3.0e38f)) q = x / d.s;     // inf / NaN: whatever the division gives
+  return q;
+}
+// 8 values -> 8 saturated e4m3 bytes (two packed converts per dword instead of one convert + mask + shift per byte)
+__device__ __forceinline__ uint2 f32x8_to_fp8x8_sat(const float (&v)[8]) {
+  float c[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = fmaxf(-kFp8Max, fminf(v[j], kFp8Max));
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], hi, true);
+  return make_uint2((uint32_t)lo, (uint32_t)hi);
+}
+__device__ __forceinline__ uint32_t f32x4_to_fp8x4_sat(const float (&v)[4]) {
+  float c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = fmaxf(-kFp8Max, fminf(v[j], kFp8Max));
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
+  return (uint32_t)w;
+}
+
 // e4m3fn byte -> float (exact; v_cvt_f32_fp8)
 __device__ __forceinline__ float fp8_to_f32(uint8_t b) {
   return __builtin_amdgcn_cvt_f32_fp8((int)b, 0);

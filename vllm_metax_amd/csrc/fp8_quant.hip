@@ -29,27 +29,33 @@ __device__ __forceinline__ void for_each_row_elem(const T* row, int n, F&& f) {
 
 template <typename T, bool VEC, bool DIVIDE>
 __device__ __forceinline__ void quant_row(uint8_t* out_row, const T* row, int n, float s) {
+  RowDiv rdiv{};
+  if constexpr (DIVIDE) rdiv = make_row_div(s);   // x / s, the bits of the division (common.cuh)
   if constexpr (VEC) {
     constexpr int V = 16 / sizeof(T);
     for (int i = threadIdx.x * V; i < n; i += blockDim.x * V) {
       T v[V];
-      uint8_t q[V];
+      float y[V];
       *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(row + i);
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         const float x = to_f32(v[j]);
-        q[j] = f32_to_fp8_sat(DIVIDE ? x / s : x * s);
+        if constexpr (DIVIDE) y[j] = row_div(x, rdiv);
+        else y[j] = x * s;
       }
       if constexpr (V == 8) {
-        *reinterpret_cast<uint2*>(out_row + i) = *reinterpret_cast<const uint2*>(q);
+        *reinterpret_cast<uint2*>(out_row + i) = f32x8_to_fp8x8_sat(y);
       } else {
-        *reinterpret_cast<uint32_t*>(out_row + i) = *reinterpret_cast<const uint32_t*>(q);
+        *reinterpret_cast<uint32_t*>(out_row + i) = f32x4_to_fp8x4_sat(y);
       }
     }
   } else {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
       const float x = to_f32(row[i]);
-      out_row[i] = f32_to_fp8_sat(DIVIDE ? x / s : x * s);
+      float y;
+      if constexpr (DIVIDE) y = row_div(x, rdiv);
+      else y = x * s;
+      out_row[i] = f32_to_fp8_sat(y);
     }
   }
 }

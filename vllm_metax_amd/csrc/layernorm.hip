@@ -127,6 +127,7 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
     __syncthreads();
     q_div = s_bcast;
   }
+  const RowDiv rdiv = make_row_div(q_div);   // (the true division, three operations per element: common.cuh)
 
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) {
@@ -146,18 +147,15 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
         }
       } else {
         uint8_t* dst = static_cast<uint8_t*>(out_v) + row * hidden_size + idx;
-        uint8_t q[V];
+        float y[V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float y = (OUT == kOutFp8Static) ? x[c][j] * q_mul : x[c][j] / q_div;
-          q[j] = f32_to_fp8_sat(y);
-        }
+        for (int j = 0; j < V; ++j) y[j] = (OUT == kOutFp8Static) ? x[c][j] * q_mul : row_div(x[c][j], rdiv);
         if constexpr (V == 8) {
-          *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(q);
+          *reinterpret_cast<uint2*>(dst) = f32x8_to_fp8x8_sat(y);
         } else if constexpr (V == 4) {
-          *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(q);
+          *reinterpret_cast<uint32_t*>(dst) = f32x4_to_fp8x4_sat(y);
         } else {
-          dst[0] = q[0];
+          dst[0] = f32_to_fp8_sat(y[0]);
         }
       }
     }

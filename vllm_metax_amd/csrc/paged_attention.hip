@@ -741,12 +741,12 @@ __global__ __launch_bounds__(1024) void paged_attention_reduce_quant_kernel(
     s_scale = sc;
   }
   __syncthreads();
-  const float sc = s_scale;
+  const RowDiv rdiv = make_row_div(s_scale);
   uint8_t* q = out_q + ((int64_t)seq * num_heads + head) * head_size;
 #pragma unroll
   for (int c = 0; c < kMaxD; ++c) {
     const int i = lane + 64 * c;
-    if (i < head_size) q[i] = f32_to_fp8_sat(to_f32(o[c]) / sc);
+    if (i < head_size) q[i] = f32_to_fp8_sat(row_div(to_f32(o[c]), rdiv));
   }
 }
 
