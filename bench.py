@@ -94,7 +94,7 @@ def parse_args():
                          "collective, weak scaling)")
     ap.add_argument("--no-dp-extra", action="store_true",
                     help="tp runs: skip the additional dp-replica measurement (the \"dp_replicas\" object)")
-    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8"],
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8", "fp8_e5m2"],
                     help="fp8: e4m3 KV cache (SURVEY §8f-3), halves the bytes decode attention streams")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true")

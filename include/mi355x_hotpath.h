@@ -51,7 +51,8 @@ enum {
  * the fp8 cache is SURVEY §8f-3, hook points csrc/cache_kernels.cu:245-253,258-269. */
 typedef enum {
   MI355X_KV_AUTO = 0,
-  MI355X_KV_FP8_E4M3 = 1
+  MI355X_KV_FP8_E4M3 = 1,
+  MI355X_KV_FP8_E5M2 = 2   /* "fp8_e5m2": e5m2 bytes, same layouts and scales as e4m3 (round 3) */
 } mi355x_kv_cache_dtype;
 
 typedef void* mi355x_stream; /* hipStream_t */
@@ -91,8 +92,9 @@ int mi355x_reshape_and_cache_flash(const void* key, const void* value, void* key
                                    int dtype, int kv_cache_dtype, const float* k_scale,
                                    const float* v_scale, mi355x_stream stream);
 
-/* convert_fp8: elementwise over a flat cache of `numel` elements.  to_fp8 != 0: src scalar_t ->
- * dst e4m3 byte = sat(float(x) / scale); else src byte -> dst scalar_t = T(float(byte) * scale).
+/* convert_fp8: elementwise over a flat cache of `numel` elements.  to_fp8 = 1: src scalar_t ->
+ * dst e4m3 byte = sat(float(x) / scale); 0: src e4m3 byte -> dst scalar_t = T(float(byte) * scale); 3 / 2: the same
+ * two directions for e5m2 bytes ("fp8_e5m2").
  * ref: csrc/cache_kernels.cu:544-612 ("only for testing" there), schema torch_bindings.cpp:424. */
 int mi355x_convert_fp8(void* dst, const void* src, int64_t numel, float scale, int to_fp8,
                        int dtype, mi355x_stream stream);

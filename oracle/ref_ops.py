@@ -87,19 +87,29 @@ def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping) -> None:
 # [nb, H, D, bs] bytes.  parity unpinned by a reference run (rejected there); the read side is
 # pinned through the reference's own test procedure (dequantise, then its torch attention
 # reference: tests/kernels/attention/test_attention.py:303-328, fixture ref_paged_attention_fp8kv).
-def fp8_quant(x: torch.Tensor, scale: float) -> torch.Tensor:
-    """scalar_t -> e4m3 bytes (uint8 tensor)."""
-    return _to_fp8_sat(x.float() / np.float32(scale)).view(torch.uint8)
+# "fp8_e5m2" (upstream vLLM's second 8-bit cache format; csrc/attention/dtype_fp8.cuh:9-13 lists kFp8E5M2 beside
+# kFp8E4M3): the same arithmetic with e5m2 bytes — byte = sat_e5m2(float(x) / scale), saturating at 57344, RNE.
+BF8 = torch.float8_e5m2
+BF8_MAX = 57344.0
 
 
-def fp8_dequant(b: torch.Tensor, scale: float, dtype) -> torch.Tensor:
-    """e4m3 bytes -> T(float(byte) * scale)."""
-    return (b.view(FP8).float() * np.float32(scale)).to(dtype)
+def fp8_quant(x: torch.Tensor, scale: float, fmt: str = "e4m3") -> torch.Tensor:
+    """scalar_t -> e4m3 (or e5m2) bytes (uint8 tensor)."""
+    y = x.float() / np.float32(scale)
+    if fmt == "e5m2":
+        return y.clamp(-BF8_MAX, BF8_MAX).to(BF8).view(torch.uint8)
+    return _to_fp8_sat(y).view(torch.uint8)
 
 
-def reshape_and_cache_fp8(key, value, key_cache, value_cache, slot_mapping, k_scale, v_scale) -> None:
-    """reshape_and_cache with kv_cache_dtype "fp8": caches are uint8, x = 16."""
-    reshape_and_cache(fp8_quant(key, k_scale), fp8_quant(value, v_scale), key_cache, value_cache, slot_mapping)
+def fp8_dequant(b: torch.Tensor, scale: float, dtype, fmt: str = "e4m3") -> torch.Tensor:
+    """e4m3 (or e5m2) bytes -> T(float(byte) * scale)."""
+    return (b.view(BF8 if fmt == "e5m2" else FP8).float() * np.float32(scale)).to(dtype)
+
+
+def reshape_and_cache_fp8(key, value, key_cache, value_cache, slot_mapping, k_scale, v_scale, fmt="e4m3") -> None:
+    """reshape_and_cache with kv_cache_dtype "fp8" / "fp8_e5m2": caches are uint8, x = 16."""
+    reshape_and_cache(fp8_quant(key, k_scale, fmt), fp8_quant(value, v_scale, fmt), key_cache, value_cache,
+                      slot_mapping)
 
 
 def reshape_and_cache_flash_fp8(key, value, key_cache, value_cache, slot_mapping, k_scale, v_scale) -> None:

@@ -77,7 +77,7 @@ def test_ops_raise_on_cpu_tensors(built):
     with pytest.raises(RuntimeError):
         ops.reshape_and_cache(x, x, x, x, torch.zeros(2, dtype=torch.int64), "fp8")
     with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
-        ops.reshape_and_cache(x, x, x, x, torch.zeros(2, dtype=torch.int64), "fp8_e5m2")
+        ops.reshape_and_cache(x, x, x, x, torch.zeros(2, dtype=torch.int64), "fp8_e3m4")
 
 
 def test_torch_bindings_register_reference_op_names(built):

@@ -105,7 +105,7 @@ def test_convert_fp8(dtype):
     got, want = back.cpu(), R.fp8_dequant(codes, 1.5, dtype)
     assert_bit_exact(got + 0.0, want + 0.0, "from fp8")
     with pytest.raises(RuntimeError):
-        ops().convert_fp8(back, codes.to(d), 1.0, "fp8_e5m2")
+        ops().convert_fp8(back, codes.to(d), 1.0, "fp8_e3m4")
 
 
 # ------------------------------------------------------------------ decode attention
@@ -200,7 +200,7 @@ def test_fp8kv_rejections():
     with pytest.raises(RuntimeError, match="block size"):
         ops().paged_attention_v1(out, q, kc, vc, 8, 1.0, bt, sl, 8, 1, None, "fp8", k_s, v_s)
     with pytest.raises(RuntimeError, match="Unsupported data type of kv cache"):
-        ops().paged_attention_v1(out, q, kc, vc, 8, 1.0, bt, sl, 8, 1, None, "fp8_e5m2", k_s, v_s)
+        ops().paged_attention_v1(out, q, kc, vc, 8, 1.0, bt, sl, 8, 1, None, "fp8_e3m4", k_s, v_s)
     with pytest.raises(RuntimeError, match="1-byte cache"):
         ops().paged_attention_v1(out, q, kc.to(BF), vc.to(BF), 8, 1.0, bt, sl, 8, 1, None, "fp8", k_s, v_s)
 
@@ -240,3 +240,94 @@ def test_paged_prefill_fp8kv(spec, ks, vs):
                                       max(q_lens), bs, "fp8", k_s, v_s)
         torch.cuda.synchronize()
         close_to_f32(out.cpu(), ref.float(), f"prefill fp8 {H}/{KVH} d{D} {dtype}", rel=2e-3 + 2.0 ** -8)
+
+
+# ------------------------------------------------------------------ e5m2 cache ("fp8_e5m2", round 3)
+BF8 = torch.float8_e5m2
+
+
+@pytest.mark.parametrize("dtype", [BF, F16, F32])
+@pytest.mark.parametrize("head_size,block_size", [(64, 16), (128, 16), (128, 32), (80, 8)])
+def test_reshape_and_cache_and_convert_e5m2(dtype, head_size, block_size):
+    """Cache write and convert_fp8 with kv_cache_dtype "fp8_e5m2" against the oracle (sat_e5m2(float(x) / scale),
+    RNE): bit-exact on the tiled and the generic path; the saturation bound 57344 is exercised."""
+    torch.manual_seed(1)
+    T, H, nb = 42, 8, 11
+    d = dev()
+    key = (torch.randn(T, H, head_size) * 2).to(dtype)
+    value = (torch.randn(T, H, head_size) * 2).to(dtype)
+    if dtype != F16:
+        key[0, 0, :2] = torch.tensor([1.0e5, -1.0e5]).to(dtype)      # saturates at +-57344 / scale
+    slots = torch.randperm(nb * block_size)[:T].to(torch.int64)
+    slots[5] = -1
+    ks, vs = 0.37, 2.0
+    kc = torch.zeros(nb, H, head_size // 16, block_size, 16, dtype=torch.uint8)
+    vc = torch.zeros(nb, H, head_size, block_size, dtype=torch.uint8)
+    R.reshape_and_cache_fp8(key, value, kc, vc, slots, ks, vs, "e5m2")
+    kd, vd = torch.zeros_like(kc, device=d), torch.zeros_like(vc, device=d)
+    k_s, v_s = _scales(ks, vs)
+    ops().reshape_and_cache(key.to(d), value.to(d), kd, vd, slots.to(d), "fp8_e5m2", k_s, v_s)
+    assert_bit_exact(kd.cpu(), kc, "key_cache")
+    assert_bit_exact(vd.cpu(), vc, "value_cache")
+    x = (torch.randn(5, 64) * 3).to(dtype)
+    b = torch.empty(x.shape, dtype=torch.uint8, device=d)
+    ops().convert_fp8(b, x.to(d), 0.7, "fp8_e5m2")
+    assert_bit_exact(b.cpu(), R.fp8_quant(x, 0.7, "e5m2"), "to e5m2")
+    codes = torch.arange(256, dtype=torch.uint8)
+    codes = codes[(codes & 0x7c) != 0x7c].repeat(4)           # every finite e5m2 code
+    back = torch.empty(codes.shape, dtype=dtype, device=d)
+    ops().convert_fp8(back, codes.to(d), 1.5, "fp8_e5m2")
+    assert_bit_exact(back.cpu() + 0.0, R.fp8_dequant(codes, 1.5, dtype, "e5m2") + 0.0, "from e5m2")
+
+
+@pytest.mark.parametrize("dtype", [BF, F16, F32])
+@pytest.mark.parametrize("heads", [(32, 8), (8, 1)])
+@pytest.mark.parametrize("ks,vs", [(1.0, 1.0), (0.5, 2.0)])
+def test_paged_attention_e5m2kv(dtype, heads, ks, vs):
+    """Decode attention over an e5m2 cache (v1 and v2) against the oracle on the dequantised cache."""
+    H, KVH = heads
+    torch.manual_seed(7)
+    D, bs, seq_lens = 128, 16, [1, 17, 300, 777]
+    S = len(seq_lens)
+    mb = (max(seq_lens) + bs - 1) // bs
+    nb = S * mb + 2
+    kc8 = (torch.rand(nb, KVH, D // 16, bs, 16) * 2 - 1).to(BF8).view(torch.uint8)
+    vc8 = (torch.rand(nb, KVH, D, bs) * 2 - 1).to(BF8).view(torch.uint8)
+    bt = torch.randperm(nb)[:S * mb].to(torch.int32).reshape(S, mb)
+    sl = torch.tensor(seq_lens, dtype=torch.int32)
+    q = (torch.randn(S, H, D) * 0.5).to(dtype)
+    m = dict(KVH=KVH, scale=D ** -0.5, bs=bs)
+    kc, vc = R.fp8_dequant(kc8, ks, dtype, "e5m2"), R.fp8_dequant(vc8, vs, dtype, "e5m2")
+    ref = R.paged_attention_v1(q, kc, vc, KVH, m["scale"], bt, sl)
+    for version in (1, 2):
+        o = _decode(m, q, kc8, vc8, bt, sl, None, version, ks, vs, name="fp8_e5m2")
+        close_to_f32(o, ref.float(), f"e5m2 v{version}", rel=1e-3 + 2.0 ** -8)
+
+
+def test_paged_prefill_e5m2kv():
+    """Prefill attention over an e5m2 cache: MFMA path (d 128, bs 16, 16-bit; plain and with a sliding window) and
+    the general kernel, against the oracle on the dequantised cache."""
+    q_lens, seq_lens = [130, 7, 64], [130, 300, 64]
+    for (H, KVH, D, bs, dtype, window) in [(8, 2, 128, 16, BF, None), (8, 2, 128, 16, F16, 96), (4, 4, 64, 16, F16, None),
+                                           (4, 2, 128, 32, F32, None)]:
+        torch.manual_seed(5)
+        S = len(q_lens)
+        mb = (max(seq_lens) + bs - 1) // bs
+        nb = S * mb + 3
+        kc8 = (torch.rand(nb, KVH, D // 16, bs, 16) * 2 - 1).to(BF8).view(torch.uint8)
+        vc8 = (torch.rand(nb, KVH, D, bs) * 2 - 1).to(BF8).view(torch.uint8)
+        bt = torch.randperm(nb)[:S * mb].to(torch.int32).reshape(S, mb)
+        cu = torch.zeros(S + 1, dtype=torch.int32)
+        cu[1:] = torch.tensor(q_lens).cumsum(0)
+        q = (torch.randn(int(cu[-1]), H, D) * 0.7).to(dtype)
+        sl = torch.tensor(seq_lens, dtype=torch.int32)
+        scale = D ** -0.5
+        ref = R.paged_prefill_attention(q, R.fp8_dequant(kc8, 0.5, dtype, "e5m2"), R.fp8_dequant(vc8, 1.7, dtype, "e5m2"),
+                                        KVH, scale, bt, sl, cu, sliding_window=window)
+        d = dev()
+        out = torch.full(q.shape, float("nan"), dtype=dtype, device=d)
+        k_s, v_s = _scales(0.5, 1.7)
+        ops().paged_prefill_attention(out, q.to(d), kc8.to(d), vc8.to(d), KVH, scale, bt.to(d), sl.to(d), cu.to(d),
+                                      max(q_lens), bs, "fp8_e5m2", k_s, v_s, window)
+        torch.cuda.synchronize()
+        close_to_f32(out.cpu(), ref.float(), f"prefill e5m2 {H}/{KVH} d{D} {dtype}", rel=2e-3 + 2.0 ** -8)

@@ -202,7 +202,7 @@ def test_torch_ops_bindings_match_ctypes_path():
                                     0, 0, 0, 64, 0)
     assert_bit_exact(o1, o2, "paged_attention_v1 binding")
     with pytest.raises(RuntimeError, match="kv cache"):
-        torch.ops._C.paged_attention_v1(o2, q, kc, vc, 1, 0.088, bt, sl, 16, 530, None, "fp8_e5m2", one, one,
+        torch.ops._C.paged_attention_v1(o2, q, kc, vc, 1, 0.088, bt, sl, 16, 530, None, "fp8_e3m4", one, one,
                                         0, 0, 0, 64, 0)
     with pytest.raises(RuntimeError, match="1-byte cache"):           # "fp8" needs an e4m3 byte cache
         torch.ops._C.paged_attention_v1(o2, q, kc, vc, 1, 0.088, bt, sl, 16, 530, None, "fp8", one, one,

@@ -15,7 +15,7 @@ PKG_DIR = Path(__file__).resolve().parent
 LIB_PATH = PKG_DIR / "libmi355x_hotpath.so"
 
 F16, BF16, F32 = 0, 1, 2
-KV_AUTO, KV_FP8_E4M3 = 0, 1          # mi355x_kv_cache_dtype
+KV_AUTO, KV_FP8_E4M3, KV_FP8_E5M2 = 0, 1, 2          # mi355x_kv_cache_dtype
 ABI_VERSION = 5                      # the MI355X_ABI_VERSION the PROTOTYPES below were written for
 
 _P = c_void_p

@@ -79,17 +79,17 @@ def _kv_dtype(kv_cache_dtype: str, cache: torch.Tensor, k_scale, v_scale):
     """`str kv_cache_dtype` of the schema -> (mi355x_kv_cache_dtype, k_scale ptr, v_scale ptr).
     "auto": the cache holds scalar_t (all the reference accepts: csrc/quantization/fp8/metax/
     quant_utils.cuh:29-42).  "fp8" / "fp8_e4m3": OCP e4m3fn bytes (upstream vLLM's
-    names), cache tensors of dtype uint8 / float8_e4m3fn, k_scale / v_scale one float32 each on the
+    names), "fp8_e5m2": e5m2 bytes (csrc/attention/dtype_fp8.cuh:9-13 lists both), cache tensors of a 1-byte dtype, k_scale / v_scale one float32 each on the
     device.  Anything else raises like the reference's TORCH_CHECK."""
     if kv_cache_dtype == "auto":
         return _abi.KV_AUTO, None, None
-    if kv_cache_dtype in ("fp8", "fp8_e4m3"):
+    if kv_cache_dtype in ("fp8", "fp8_e4m3", "fp8_e5m2"):
         if cache.element_size() != 1:
             raise RuntimeError(f"kv_cache_dtype {kv_cache_dtype!r} needs a 1-byte cache, got {cache.dtype}")
         for name, t in (("k_scale", k_scale), ("v_scale", v_scale)):
             if t is None or not t.is_cuda or t.dtype != torch.float32 or t.numel() != 1:
                 raise RuntimeError(f"{name} must be one float32 element on the GPU for an fp8 KV cache")
-        return _abi.KV_FP8_E4M3, _ptr(k_scale), _ptr(v_scale)
+        return (_abi.KV_FP8_E5M2 if kv_cache_dtype == "fp8_e5m2" else _abi.KV_FP8_E4M3), _ptr(k_scale), _ptr(v_scale)
     raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
 
 
@@ -152,7 +152,7 @@ def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0,
     """torch.ops._C_cache_ops.convert_fp8 (csrc/torch_bindings.cpp:424-426, cache_kernels.cu:564-612):
     elementwise over the flat cache; direction from the dtypes (1-byte side = e4m3 bytes)."""
     _dev(output, input)
-    if kv_dtype not in ("fp8", "fp8_e4m3"):
+    if kv_dtype not in ("fp8", "fp8_e4m3", "fp8_e5m2"):
         raise RuntimeError(f"Unsupported data type: {kv_dtype}")
     if output.numel() != input.numel() or not (output.is_contiguous() and input.is_contiguous()):
         raise RuntimeError("convert_fp8: tensors must be contiguous and of the same size")
@@ -161,7 +161,8 @@ def convert_fp8(output: torch.Tensor, input: torch.Tensor, scale: float = 1.0,
     if (input if to_fp8 else output).element_size() == 1 or (output if to_fp8 else input).element_size() != 1:
         raise RuntimeError("convert_fp8: exactly one of the tensors must be a 1-byte (fp8) tensor")
     rc = _abi.load().mi355x_convert_fp8(_ptr(output), _ptr(input), input.numel(), float(scale),
-                                        1 if to_fp8 else 0, _dt(wide), _stream())
+                                        (1 if to_fp8 else 0) + (2 if kv_dtype == "fp8_e5m2" else 0), _dt(wide),
+                                        _stream())
     _abi.check(rc, "convert_fp8")
 
 

@@ -173,7 +173,7 @@ __global__ void reshape_and_cache_flash_kernel(
 // ---------------------------------------------------------------------------
 // fp8 (e4m3fn) cache.  key_cache [nb, heads, d/16, bs, 16] bytes (x = 16 / sizeof(cache_t) = 16),
 // value_cache [nb, heads, d, bs] bytes.  byte = sat_e4m3(float(x) / *scale), RNE.
-template <typename T>
+template <typename T, bool E5M2 = false>
 __device__ __forceinline__ uint4 quant16(const T* __restrict__ src, float scale) {
   // 16 consecutive elements -> 16 fp8 bytes
   constexpr int X = 16 / sizeof(T);
@@ -187,14 +187,14 @@ __device__ __forceinline__ uint4 quant16(const T* __restrict__ src, float scale)
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    w[i] = (uint32_t)f32x2_to_fp8x2_sat(f[4 * i], f[4 * i + 1]) |
-           ((uint32_t)f32x2_to_fp8x2_sat(f[4 * i + 2], f[4 * i + 3]) << 16);
+    w[i] = (uint32_t)Kv8Fmt<E5M2>::to8x2(f[4 * i], f[4 * i + 1]) |
+           ((uint32_t)Kv8Fmt<E5M2>::to8x2(f[4 * i + 2], f[4 * i + 3]) << 16);
   }
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // Tiled path: grid (ceil(T/16), num_heads), 256 threads; head_size % 16 == 0, 16-B aligned rows.
-template <typename T>
+template <typename T, bool E5M2 = false>
 __global__ __launch_bounds__(256) void reshape_and_cache_fp8_tiled_kernel(
     const T* __restrict__ key, const T* __restrict__ value, uint8_t* __restrict__ key_cache,
     uint8_t* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, int num_tokens,
@@ -223,10 +223,10 @@ __global__ __launch_bounds__(256) void reshape_and_cache_fp8_tiled_kernel(
     const int64_t blk = s_blk[j];
     if (blk < 0) continue;
     const int t = t0 + j;
-    const uint4 kq = quant16<T>(key + t * key_stride + (int64_t)head * head_size + c * 16, ks);
+    const uint4 kq = quant16<T, E5M2>(key + t * key_stride + (int64_t)head * head_size + c * 16, ks);
     uint8_t* kdst = key_cache + (((blk * num_heads + head) * chunks + c) * block_size + s_off[j]) * 16;
     *reinterpret_cast<uint4*>(kdst) = kq;
-    const uint4 vq = quant16<T>(value + t * value_stride + (int64_t)head * head_size + c * 16, vs);
+    const uint4 vq = quant16<T, E5M2>(value + t * value_stride + (int64_t)head * head_size + c * 16, vs);
     *reinterpret_cast<uint4*>(vt + j * row + c * 16) = vq;
   }
   __syncthreads();
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void reshape_and_cache_fp8_tiled_kernel(
   }
 }
 
-template <typename T>
+template <typename T, bool E5M2 = false>
 __global__ void reshape_and_cache_fp8_generic_kernel(
     const T* __restrict__ key, const T* __restrict__ value, uint8_t* __restrict__ key_cache,
     uint8_t* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, int64_t key_stride,
@@ -259,12 +259,12 @@ __global__ void reshape_and_cache_fp8_generic_kernel(
     const int xo = ho % x;
     const int64_t kdst = (((blk * num_heads + head) * (head_size / x) + xi) * block_size + off) * x + xo;
     const int64_t vdst = ((blk * num_heads + head) * head_size + ho) * block_size + off;
-    key_cache[kdst] = f32_to_fp8_sat(to_f32(key[token * key_stride + i]) / ks);
-    value_cache[vdst] = f32_to_fp8_sat(to_f32(value[token * value_stride + i]) / vs);
+    key_cache[kdst] = Kv8Fmt<E5M2>::to8(to_f32(key[token * key_stride + i]) / ks);
+    value_cache[vdst] = Kv8Fmt<E5M2>::to8(to_f32(value[token * value_stride + i]) / vs);
   }
 }
 
-template <typename T>
+template <typename T, bool E5M2 = false>
 __global__ void reshape_and_cache_flash_fp8_kernel(
     const T* __restrict__ key, const T* __restrict__ value, uint8_t* __restrict__ key_cache,
     uint8_t* __restrict__ value_cache, const int64_t* __restrict__ slot_mapping, int64_t block_stride,
@@ -285,22 +285,22 @@ __global__ void reshape_and_cache_flash_fp8_kernel(
     const int head = i / head_size;
     const int d = i - head * head_size;
     const int64_t dof = (int64_t)head * head_stride + d;
-    kdst[dof] = f32_to_fp8_sat(to_f32(ksrc[i]) / ks);
-    vdst[dof] = f32_to_fp8_sat(to_f32(vsrc[i]) / vs);
+    kdst[dof] = Kv8Fmt<E5M2>::to8(to_f32(ksrc[i]) / ks);
+    vdst[dof] = Kv8Fmt<E5M2>::to8(to_f32(vsrc[i]) / vs);
   }
 }
 
 // convert_fp8 (csrc/cache_kernels.cu:544-612, "only for testing" there): elementwise over the flat
 // cache, either direction.
-template <typename T, bool TO_FP8>
+template <typename T, bool TO_FP8, bool E5M2 = false>
 __global__ void convert_fp8_kernel(void* __restrict__ dst, const void* __restrict__ src, float scale,
                                    int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     if constexpr (TO_FP8) {
-      static_cast<uint8_t*>(dst)[i] = f32_to_fp8_sat(to_f32(static_cast<const T*>(src)[i]) / scale);
+      static_cast<uint8_t*>(dst)[i] = Kv8Fmt<E5M2>::to8(to_f32(static_cast<const T*>(src)[i]) / scale);
     } else {
-      static_cast<T*>(dst)[i] = from_f32<T>(fp8_to_f32(static_cast<const uint8_t*>(src)[i]) * scale);
+      static_cast<T*>(dst)[i] = from_f32<T>(Kv8Fmt<E5M2>::from8(static_cast<const uint8_t*>(src)[i]) * scale);
     }
   }
 }
@@ -345,7 +345,8 @@ int mi355x_reshape_and_cache(const void* key, const void* value, void* key_cache
                              const float* v_scale, mi355x_stream stream) {
   MI355X_REQUIRE(num_tokens >= 0 && num_heads > 0 && head_size > 0 && block_size > 0 && x > 0,
                  MI355X_EINVAL, "reshape_and_cache: bad sizes");
-  MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3,
+  MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3 ||
+                     kv_cache_dtype == MI355X_KV_FP8_E5M2,
                  MI355X_EUNSUPPORTED, "Unsupported data type of kv cache: id %d", kv_cache_dtype);
   MI355X_REQUIRE(head_size % x == 0, MI355X_EINVAL,
                  "reshape_and_cache: head_size %d not a multiple of x %d", head_size, x);
@@ -353,7 +354,8 @@ int mi355x_reshape_and_cache(const void* key, const void* value, void* key_cache
   MI355X_REQUIRE(key && value && key_cache && value_cache && slot_mapping, MI355X_EINVAL,
                  "reshape_and_cache: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (kv_cache_dtype == MI355X_KV_FP8_E4M3) {
+  if (kv_cache_dtype != MI355X_KV_AUTO) {
+    const bool e5m2 = kv_cache_dtype == MI355X_KV_FP8_E5M2;
     MI355X_REQUIRE(k_scale && v_scale, MI355X_EINVAL, "reshape_and_cache: fp8 cache needs k_scale / v_scale");
     return MI355X_DISPATCH_FLOAT(dtype, [&] {
       constexpr int X = 16 / sizeof(scalar_t);
@@ -366,15 +368,25 @@ int mi355x_reshape_and_cache(const void* key, const void* value, void* key_cache
       if (vec) {
         dim3 grid((num_tokens + kTokTile - 1) / kTokTile, num_heads);
         size_t smem = (size_t)kTokTile * (head_size + 16) + kTokTile * (sizeof(int64_t) + sizeof(int));
-        hipLaunchKernelGGL(reshape_and_cache_fp8_tiled_kernel<scalar_t>, grid, dim3(256), smem, s, k, v,
-                           kc, vc, slot_mapping, num_tokens, key_stride, value_stride, num_heads,
-                           head_size, block_size, k_scale, v_scale);
+        if (e5m2)
+          hipLaunchKernelGGL((reshape_and_cache_fp8_tiled_kernel<scalar_t, true>), grid, dim3(256), smem, s, k, v,
+                             kc, vc, slot_mapping, num_tokens, key_stride, value_stride, num_heads,
+                             head_size, block_size, k_scale, v_scale);
+        else
+          hipLaunchKernelGGL((reshape_and_cache_fp8_tiled_kernel<scalar_t, false>), grid, dim3(256), smem, s, k, v,
+                             kc, vc, slot_mapping, num_tokens, key_stride, value_stride, num_heads,
+                             head_size, block_size, k_scale, v_scale);
       } else {
         int threads = num_heads * head_size < 512 ? num_heads * head_size : 512;
         threads = ((threads + 63) / 64) * 64;
-        hipLaunchKernelGGL(reshape_and_cache_fp8_generic_kernel<scalar_t>, dim3(num_tokens),
-                           dim3(threads), 0, s, k, v, kc, vc, slot_mapping, key_stride, value_stride,
-                           num_heads, head_size, block_size, x, k_scale, v_scale);
+        if (e5m2)
+          hipLaunchKernelGGL((reshape_and_cache_fp8_generic_kernel<scalar_t, true>), dim3(num_tokens),
+                             dim3(threads), 0, s, k, v, kc, vc, slot_mapping, key_stride, value_stride,
+                             num_heads, head_size, block_size, x, k_scale, v_scale);
+        else
+          hipLaunchKernelGGL((reshape_and_cache_fp8_generic_kernel<scalar_t, false>), dim3(num_tokens),
+                             dim3(threads), 0, s, k, v, kc, vc, slot_mapping, key_stride, value_stride,
+                             num_heads, head_size, block_size, x, k_scale, v_scale);
       }
       return check_launch("reshape_and_cache(fp8)");
     });
@@ -443,23 +455,32 @@ int mi355x_reshape_and_cache_flash(const void* key, const void* value, void* key
                                    const float* v_scale, mi355x_stream stream) {
   MI355X_REQUIRE(num_tokens >= 0 && num_heads > 0 && head_size > 0 && block_size > 0,
                  MI355X_EINVAL, "reshape_and_cache_flash: bad sizes");
-  MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3,
+  MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3 ||
+                     kv_cache_dtype == MI355X_KV_FP8_E5M2,
                  MI355X_EUNSUPPORTED, "Unsupported data type of kv cache: id %d", kv_cache_dtype);
   if (num_tokens == 0) return MI355X_OK;
   MI355X_REQUIRE(key && value && key_cache && value_cache && slot_mapping, MI355X_EINVAL,
                  "reshape_and_cache_flash: null pointer");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (kv_cache_dtype == MI355X_KV_FP8_E4M3) {
+  if (kv_cache_dtype != MI355X_KV_AUTO) {
+    const bool e5m2 = kv_cache_dtype == MI355X_KV_FP8_E5M2;
     MI355X_REQUIRE(k_scale && v_scale, MI355X_EINVAL,
                    "reshape_and_cache_flash: fp8 cache needs k_scale / v_scale");
     return MI355X_DISPATCH_FLOAT(dtype, [&] {
       int work = num_heads * head_size;
       int threads = work < 256 ? ((work + 63) / 64) * 64 : 256;
-      hipLaunchKernelGGL(reshape_and_cache_flash_fp8_kernel<scalar_t>, dim3(num_tokens), dim3(threads),
-                         0, s, static_cast<const scalar_t*>(key), static_cast<const scalar_t*>(value),
-                         static_cast<uint8_t*>(key_cache), static_cast<uint8_t*>(value_cache),
-                         slot_mapping, block_stride, page_stride, head_stride, key_stride,
-                         value_stride, num_heads, head_size, block_size, k_scale, v_scale);
+      if (e5m2)
+        hipLaunchKernelGGL((reshape_and_cache_flash_fp8_kernel<scalar_t, true>), dim3(num_tokens), dim3(threads),
+                           0, s, static_cast<const scalar_t*>(key), static_cast<const scalar_t*>(value),
+                           static_cast<uint8_t*>(key_cache), static_cast<uint8_t*>(value_cache),
+                           slot_mapping, block_stride, page_stride, head_stride, key_stride,
+                           value_stride, num_heads, head_size, block_size, k_scale, v_scale);
+      else
+        hipLaunchKernelGGL((reshape_and_cache_flash_fp8_kernel<scalar_t, false>), dim3(num_tokens), dim3(threads),
+                           0, s, static_cast<const scalar_t*>(key), static_cast<const scalar_t*>(value),
+                           static_cast<uint8_t*>(key_cache), static_cast<uint8_t*>(value_cache),
+                           slot_mapping, block_stride, page_stride, head_stride, key_stride,
+                           value_stride, num_heads, head_size, block_size, k_scale, v_scale);
       return check_launch("reshape_and_cache_flash(fp8)");
     });
   }
@@ -498,11 +519,18 @@ int mi355x_convert_fp8(void* dst, const void* src, int64_t numel, float scale, i
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int blocks = (int)((numel + 255) / 256 < 4096 ? (numel + 255) / 256 : 4096);
   return MI355X_DISPATCH_FLOAT(dtype, [&] {
-    if (to_fp8) {
+    // to_fp8: 0 = e4m3 bytes -> T, 1 = T -> e4m3 bytes, 2 = e5m2 bytes -> T, 3 = T -> e5m2 bytes (2 / 3: round 3)
+    if (to_fp8 == 1) {
       hipLaunchKernelGGL((convert_fp8_kernel<scalar_t, true>), dim3(blocks), dim3(256), 0, s, dst, src,
                          scale, numel);
-    } else {
+    } else if (to_fp8 == 0) {
       hipLaunchKernelGGL((convert_fp8_kernel<scalar_t, false>), dim3(blocks), dim3(256), 0, s, dst, src,
+                         scale, numel);
+    } else if (to_fp8 == 3) {
+      hipLaunchKernelGGL((convert_fp8_kernel<scalar_t, true, true>), dim3(blocks), dim3(256), 0, s, dst, src,
+                         scale, numel);
+    } else {
+      hipLaunchKernelGGL((convert_fp8_kernel<scalar_t, false, true>), dim3(blocks), dim3(256), 0, s, dst, src,
                          scale, numel);
     }
     return check_launch("convert_fp8");

@@ -276,6 +276,39 @@ __device__ __forceinline__ float fp8_to_f32(uint8_t b) {
   return __builtin_amdgcn_cvt_f32_fp8((int)b, 0);
 }
 
+// ---- fp8 e5m2 (OCP "bf8"): the second 8-bit KV-cache format (kv_cache_dtype "fp8_e5m2", upstream vLLM's name; listed
+// by the reference at csrc/attention/dtype_fp8.cuh:9-13 and rejected by its dispatch like e4m3).  Saturating finite
+// conversion (max 57344), RNE — v_cvt_pk_bf8_f32.
+struct e5m2_t {             // cache element tag: one e5m2 byte
+  uint8_t v;
+  e5m2_t() = default;
+  __host__ __device__ explicit e5m2_t(int x) : v(static_cast<uint8_t>(x)) {}
+};
+constexpr float kBf8Max = 57344.0f;
+__device__ __forceinline__ uint8_t f32_to_bf8_sat(float x) {
+  float r = fmaxf(-kBf8Max, fminf(x, kBf8Max));
+  int packed = __builtin_amdgcn_cvt_pk_bf8_f32(r, r, 0, false);
+  return static_cast<uint8_t>(packed & 0xff);
+}
+__device__ __forceinline__ uint16_t f32x2_to_bf8x2_sat(float a, float b) {
+  float ra = fmaxf(-kBf8Max, fminf(a, kBf8Max));
+  float rb = fmaxf(-kBf8Max, fminf(b, kBf8Max));
+  int packed = __builtin_amdgcn_cvt_pk_bf8_f32(ra, rb, 0, false);
+  return static_cast<uint16_t>(packed & 0xffff);
+}
+__device__ __forceinline__ float bf8_to_f32(uint8_t b) {
+  return __builtin_amdgcn_cvt_f32_bf8((int)b, 0);
+}
+// the two byte formats behind one switch (E5M2 = false: e4m3fn)
+template <bool E5M2>
+struct Kv8Fmt {
+  static __device__ __forceinline__ uint8_t to8(float x) { return E5M2 ? f32_to_bf8_sat(x) : f32_to_fp8_sat(x); }
+  static __device__ __forceinline__ uint16_t to8x2(float a, float b) {
+    return E5M2 ? f32x2_to_bf8x2_sat(a, b) : f32x2_to_fp8x2_sat(a, b);
+  }
+  static __device__ __forceinline__ float from8(uint8_t b) { return E5M2 ? bf8_to_f32(b) : fp8_to_f32(b); }
+};
+
 // ---- split-K slab sum ------------------------------------------------------------
 // acc[j] = slab[0][j] + slab[1][j] + ... + slab[sk-1][j] in THAT order (the consumers of the
 // decode GEMM's fp32 partials must all round the same sum), V consecutive floats per lane.  The

@@ -116,47 +116,57 @@ __device__ __forceinline__ float dot_chunk<float>(const uint4& a, const uint4& b
   return acc;
 }
 
-// 16 e4m3 bytes -> 16 scalar_t values (QP = 16 * sizeof(T) / 16 uint4s), exact.
-template <typename T>
+// 16 e4m3 (E5M2: e5m2) bytes -> 16 scalar_t values (QP = 16 * sizeof(T) / 16 uint4s), exact.
+template <typename T, bool E5M2 = false>
 struct Fp8Piece;
-template <>
-struct Fp8Piece<bf16_t> {
+template <bool E5M2>
+struct Fp8Piece<bf16_t, E5M2> {
   static constexpr int QP = 2;
   static __device__ __forceinline__ void cvt(const uint4& r, uint4 (&t)[2]) {
     auto lo = [](uint32_t w) {
-      return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
+      if constexpr (E5M2) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(w, 1.0f, false));
+      else return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false));
     };
     auto hi = [](uint32_t w) {
-      return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true));
+      if constexpr (E5M2) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(w, 1.0f, true));
+      else return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true));
     };
     t[0] = make_uint4(lo(r.x), hi(r.x), lo(r.y), hi(r.y));
     t[1] = make_uint4(lo(r.z), hi(r.z), lo(r.w), hi(r.w));
   }
 };
-template <>
-struct Fp8Piece<f16_t> {
+template <bool E5M2>
+struct Fp8Piece<f16_t, E5M2> {
   static constexpr int QP = 2;
   static __device__ __forceinline__ void cvt(const uint4& r, uint4 (&t)[2]) {
     auto lo = [](uint32_t w) {
-      return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false));
+      if constexpr (E5M2) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(w, 1.0f, false));
+      else return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false));
     };
     auto hi = [](uint32_t w) {
-      return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true));
+      if constexpr (E5M2) return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(w, 1.0f, true));
+      else return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true));
     };
     t[0] = make_uint4(lo(r.x), hi(r.x), lo(r.y), hi(r.y));
     t[1] = make_uint4(lo(r.z), hi(r.z), lo(r.w), hi(r.w));
   }
 };
-template <>
-struct Fp8Piece<float> {
+template <bool E5M2>
+struct Fp8Piece<float, E5M2> {
   static constexpr int QP = 4;
   static __device__ __forceinline__ void cvt(const uint4& r, uint4 (&t)[4]) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false);
-      const f32x2 b = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);
+      f32x2 a, b;
+      if constexpr (E5M2) {
+        a = __builtin_amdgcn_cvt_pk_f32_bf8(w[i], false);
+        b = __builtin_amdgcn_cvt_pk_f32_bf8(w[i], true);
+      } else {
+        a = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false);
+        b = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);
+      }
       t[i] = make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(b.x),
                         __float_as_uint(b.y));
     }
@@ -166,10 +176,11 @@ struct Fp8Piece<float> {
 // One 16-B cache piece as scalar_t values: CT == T -> the piece itself; CT == uint8_t -> converted.
 template <typename T, typename CT>
 struct Piece {
-  static constexpr int QP = std::is_same<T, CT>::value ? 1 : Fp8Piece<T>::QP;
+  static constexpr bool kE5M2 = std::is_same<CT, e5m2_t>::value;
+  static constexpr int QP = std::is_same<T, CT>::value ? 1 : Fp8Piece<T, kE5M2>::QP;
   static __device__ __forceinline__ void cvt(const uint4& r, uint4 (&t)[QP]) {
     if constexpr (std::is_same<T, CT>::value) t[0] = r;
-    else Fp8Piece<T>::cvt(r, t);
+    else Fp8Piece<T, kE5M2>::cvt(r, t);
   }
   static __device__ __forceinline__ float dot(const uint4 (&a)[QP], const uint4 (&b)[QP], float acc) {
 #pragma unroll
@@ -868,6 +879,15 @@ static int launch_pa_bs(const PaArgs& a) {
 
 template <typename T>
 static int launch_pa(const PaArgs& a) {
+  if (a.kv_cache_dtype == MI355X_KV_FP8_E5M2) {
+    switch (a.block_size) {
+      case 16: return launch_pa_bs<T, e5m2_t, 16>(a);
+      case 32: return launch_pa_bs<T, e5m2_t, 32>(a);
+      default:
+        set_error("Unsupported block size with an fp8 KV cache: %d (16 or 32)", a.block_size);
+        return MI355X_EUNSUPPORTED;
+    }
+  }
   if (a.kv_cache_dtype == MI355X_KV_FP8_E4M3) {
     switch (a.block_size) {   // a 16-byte piece of the byte cache is 16 tokens of a V row
       case 16: return launch_pa_bs<T, uint8_t, 16>(a);
@@ -907,9 +927,10 @@ static int validate_pa(const PaArgs& a, const char* name) {
                  a.num_seqs);
   // ref: csrc/quantization/fp8/metax/quant_utils.cuh:29-42 rejects everything but "auto"; the
   // e4m3 cache is this build's SURVEY §8f-3 row (upstream vLLM's "fp8" / "fp8_e4m3")
-  MI355X_REQUIRE(a.kv_cache_dtype == MI355X_KV_AUTO || a.kv_cache_dtype == MI355X_KV_FP8_E4M3,
+  MI355X_REQUIRE(a.kv_cache_dtype == MI355X_KV_AUTO || a.kv_cache_dtype == MI355X_KV_FP8_E4M3 ||
+                     a.kv_cache_dtype == MI355X_KV_FP8_E5M2,
                  MI355X_EUNSUPPORTED, "Unsupported data type of kv cache: id %d", a.kv_cache_dtype);
-  if (a.kv_cache_dtype == MI355X_KV_FP8_E4M3) {
+  if (a.kv_cache_dtype != MI355X_KV_AUTO) {
     MI355X_REQUIRE(a.k_scale && a.v_scale, MI355X_EINVAL, "%s: fp8 KV cache needs k_scale / v_scale", name);
     MI355X_REQUIRE(a.head_size % 16 == 0, MI355X_EUNSUPPORTED,
                    "%s: fp8 KV cache needs head_size %% 16 == 0 (got %d)", name, a.head_size);

@@ -42,11 +42,17 @@ struct MfmaQK<bf16_t> {
     bf16x2_t v = {static_cast<bf16_t>(lo), static_cast<bf16_t>(hi)};
     return __builtin_bit_cast(uint32_t, v);
   }
-  // 4 e4m3 bytes -> 4 bf16 (two packed words), exact
+  // 4 e4m3 (E5M2: e5m2) bytes -> 4 bf16 (two packed words), exact
+  template <bool E5M2 = false>
   static __device__ __forceinline__ uint2 from_fp8x4(uint32_t w) {
-    return make_uint2(
-        __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false)),
-        __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true)));
+    if constexpr (E5M2)
+      return make_uint2(
+          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(w, 1.0f, false)),
+          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_bf8(w, 1.0f, true)));
+    else
+      return make_uint2(
+          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, false)),
+          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w, 1.0f, true)));
   }
 };
 template <>
@@ -59,10 +65,16 @@ struct MfmaQK<f16_t> {
     f16x2_t v = {static_cast<f16_t>(lo), static_cast<f16_t>(hi)};
     return __builtin_bit_cast(uint32_t, v);
   }
+  template <bool E5M2 = false>
   static __device__ __forceinline__ uint2 from_fp8x4(uint32_t w) {
-    return make_uint2(
-        __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false)),
-        __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true)));
+    if constexpr (E5M2)
+      return make_uint2(
+          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(w, 1.0f, false)),
+          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_bf8(w, 1.0f, true)));
+    else
+      return make_uint2(
+          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, false)),
+          __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 1.0f, true)));
   }
 };
 
@@ -104,7 +116,7 @@ constexpr float kNegBig = -1.0e30f;
 // tests/kernels/attention/test_flash_attn.py:60-67), ALiBi adds slope[head] * (key - query position) to the
 // scaled score (the bias of the decode kernel, attention_kernels.cuh:286, at every query position).  A separate
 // instantiation: the plain causal path keeps its register count.
-template <typename T, bool KV8, bool IMG = false, bool OPTS = false>
+template <typename T, bool KV8, bool IMG = false, bool OPTS = false, bool E5M2 = false>
 __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     T* __restrict__ out, const T* __restrict__ q, const void* __restrict__ k_cache_v,
     const void* __restrict__ v_cache_v, int num_heads, int num_kv_heads, float scale,
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
             // d = 32 ds + 8 lr + j -> piece 2 ds + (lr >> 1), bytes 8 (lr & 1) .. +7 of token lc
             const uint2 raw = *reinterpret_cast<const uint2*>(
                 sbuf + b * 2048 + ((2 * ds + (lr >> 1)) * 16 + lc) * 16 + 8 * (lr & 1));
-            const uint2 lo = MfmaQK<T>::from_fp8x4(raw.x), hi = MfmaQK<T>::from_fp8x4(raw.y);
+            const uint2 lo = MfmaQK<T>::template from_fp8x4<E5M2>(raw.x), hi = MfmaQK<T>::template from_fp8x4<E5M2>(raw.y);
             kf = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
 #pragma unroll
@@ -417,9 +429,9 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
           v0 = vbuf[(0 * 4096 + (16 * dt + lc) * 32 + 8 * lr) / 8];
           v1 = vbuf[(1 * 4096 + (16 * dt + lc) * 32 + 8 * lr) / 8];
         } else {   // V block image [128 d][16 keys] bytes: row 16 dt + lc, keys 4 lr .. 4 lr + 3
-          v0 = MfmaQK<T>::from_fp8x4(*reinterpret_cast<const uint32_t*>(
+          v0 = MfmaQK<T>::template from_fp8x4<E5M2>(*reinterpret_cast<const uint32_t*>(
               sbuf + 4096 + (16 * dt + lc) * 16 + 4 * lr));
-          v1 = MfmaQK<T>::from_fp8x4(*reinterpret_cast<const uint32_t*>(
+          v1 = MfmaQK<T>::template from_fp8x4<E5M2>(*reinterpret_cast<const uint32_t*>(
               sbuf + 6144 + (16 * dt + lc) * 16 + 4 * lr));
         }
         const uint4 vf = make_uint4(v0.x, v0.y, v1.x, v1.y);
@@ -471,7 +483,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
 // lanes stride over keys, two passes (max+sum, then PV).  Correctness path only.
 template <typename CT>
 __device__ __forceinline__ float cache_to_f32(CT v) {
-  if constexpr (sizeof(CT) == 1) return fp8_to_f32((uint8_t)v);
+  if constexpr (std::is_same<CT, e5m2_t>::value) return bf8_to_f32(v.v);
+  else if constexpr (sizeof(CT) == 1) return fp8_to_f32((uint8_t)v);
   else return to_f32(v);
 }
 
@@ -562,9 +575,11 @@ static int paged_prefill_impl(
     const float* alibi_slopes = nullptr) {
   MI355X_REQUIRE(sliding_window >= 0 && softcap >= 0.f, MI355X_EINVAL,
                  "paged_prefill_attention: sliding_window / softcap must be >= 0 (0 = off)");
-  MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3,
+  MI355X_REQUIRE(kv_cache_dtype == MI355X_KV_AUTO || kv_cache_dtype == MI355X_KV_FP8_E4M3 ||
+                     kv_cache_dtype == MI355X_KV_FP8_E5M2,
                  MI355X_EUNSUPPORTED, "Unsupported data type of kv cache: id %d", kv_cache_dtype);
-  const bool kv8 = kv_cache_dtype == MI355X_KV_FP8_E4M3;
+  const bool kv8 = kv_cache_dtype != MI355X_KV_AUTO;
+  const bool e5m2 = kv_cache_dtype == MI355X_KV_FP8_E5M2;
   MI355X_REQUIRE(!kv8 || (k_scale && v_scale), MI355X_EINVAL,
                  "paged_prefill_attention: fp8 KV cache needs k_scale / v_scale");
   MI355X_REQUIRE(!kv8 || head_size % 16 == 0, MI355X_EUNSUPPORTED,
@@ -596,7 +611,14 @@ static int paged_prefill_impl(
     const size_t smem = (size_t)kPfStages * 4 * (kv8 ? 2048 : 4096);   // ring of 16- / 8-KiB stages
     return MI355X_DISPATCH_HALF(dtype, [&] {
       if (image) {
-        if (kv8) {
+        if (kv8 && e5m2) {
+          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, true, false, true>), grid, block, smem, s,
+                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
+                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
+                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
+                             kv_block_stride, kv_head_stride, k_scale, v_scale, positions,
+                             static_cast<const scalar_t*>(cos_sin_cache));
+        } else if (kv8) {
           hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, true>), grid, block, smem, s,
                              static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
                              value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
@@ -614,7 +636,14 @@ static int paged_prefill_impl(
         return check_launch("paged_prefill_attention_image");
       }
       if (opts) {
-        if (kv8) {
+        if (kv8 && e5m2) {
+          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, false, true, true>), grid, block, smem, s,
+                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
+                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
+                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
+                             kv_block_stride, kv_head_stride, k_scale, v_scale, nullptr, nullptr,
+                             sliding_window, softcap, alibi_slopes);
+        } else if (kv8) {
           hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, false, true>), grid, block, smem, s,
                              static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
                              value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
@@ -631,7 +660,13 @@ static int paged_prefill_impl(
         }
         return check_launch("paged_prefill_attention(opts)");
       }
-      if (kv8) {
+      if (kv8 && e5m2) {
+        hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, false, false, true>), grid, block, smem, s,
+                           static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
+                           value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
+                           cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
+                           kv_block_stride, kv_head_stride, k_scale, v_scale);
+      } else if (kv8) {
         hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true>), grid, block, smem, s,
                            static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
                            value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
@@ -652,7 +687,15 @@ static int paged_prefill_impl(
   MI355X_REQUIRE(max_tokens <= 0x7fffffff, MI355X_EUNSUPPORTED, "paged_prefill_attention: too many tokens");
   dim3 grid((int)max_tokens, num_heads), block(64);
   return MI355X_DISPATCH_FLOAT(dtype, [&] {
-    if (kv8) {
+    if (kv8 && e5m2) {
+      hipLaunchKernelGGL((paged_prefill_generic_kernel<scalar_t, e5m2_t>), grid, block,
+                         (size_t)head_size * sizeof(float), s, static_cast<scalar_t*>(out),
+                         static_cast<const scalar_t*>(query), static_cast<const e5m2_t*>(key_cache),
+                         static_cast<const e5m2_t*>(value_cache), num_heads, num_kv_heads, head_size,
+                         block_size, scale, block_tables, seq_lens, cu_seqlens_q, num_seqs,
+                         max_num_blocks_per_seq, q_stride, out_stride, kv_block_stride,
+                         kv_head_stride, k_scale, v_scale, sliding_window, softcap);
+    } else if (kv8) {
       hipLaunchKernelGGL((paged_prefill_generic_kernel<scalar_t, uint8_t>), grid, block,
                          (size_t)head_size * sizeof(float), s, static_cast<scalar_t*>(out),
                          static_cast<const scalar_t*>(query), static_cast<const uint8_t*>(key_cache),

@@ -58,12 +58,12 @@ inline const T* cptr(const std::optional<Tensor>& t) {
 inline int kv_dtype(const std::string& s, const Tensor& cache, const Tensor& k_scale,
                     const Tensor& v_scale) {
   if (s == "auto") return MI355X_KV_AUTO;
-  TORCH_CHECK(s == "fp8" || s == "fp8_e4m3", "Unsupported data type of kv cache: ", s);
+  TORCH_CHECK(s == "fp8" || s == "fp8_e4m3" || s == "fp8_e5m2", "Unsupported data type of kv cache: ", s);
   TORCH_CHECK(cache.element_size() == 1, "kv_cache_dtype ", s, " needs a 1-byte cache tensor");
   TORCH_CHECK(k_scale.is_cuda() && v_scale.is_cuda() && k_scale.scalar_type() == at::kFloat &&
                   v_scale.scalar_type() == at::kFloat && k_scale.numel() == 1 && v_scale.numel() == 1,
               "k_scale / v_scale must be one float32 element each on the GPU");
-  return MI355X_KV_FP8_E4M3;
+  return s == "fp8_e5m2" ? MI355X_KV_FP8_E5M2 : MI355X_KV_FP8_E4M3;
 }
 inline const float* scale_ptr(int kvd, const Tensor& t) {
   return kvd == MI355X_KV_AUTO ? nullptr : t.data_ptr<float>();
@@ -578,8 +578,8 @@ void convert_fp8(Tensor& dst_cache, Tensor& src_cache, double scale, const std::
   TORCH_CHECK(src_cache.is_cuda(), "src must be on a GPU");
   TORCH_CHECK(dst_cache.is_cuda(), "dst must be on a GPU");
   TORCH_CHECK(src_cache.get_device() == dst_cache.get_device(), "src and dst must be on the same GPU");
-  TORCH_CHECK(kv_cache_dtype == "fp8" || kv_cache_dtype == "fp8_e4m3", "Unsupported data type: ",
-              kv_cache_dtype);
+  TORCH_CHECK(kv_cache_dtype == "fp8" || kv_cache_dtype == "fp8_e4m3" || kv_cache_dtype == "fp8_e5m2",
+              "Unsupported data type: ", kv_cache_dtype);
   TORCH_CHECK(src_cache.numel() == dst_cache.numel() && src_cache.is_contiguous() &&
                   dst_cache.is_contiguous(),
               "convert_fp8: contiguous tensors of equal size expected");
@@ -589,7 +589,8 @@ void convert_fp8(Tensor& dst_cache, Tensor& src_cache, double scale, const std::
               "convert_fp8: exactly one side must be a 1-byte (fp8) tensor");
   Guard g(src_cache);
   ok(mi355x_convert_fp8(dst_cache.data_ptr(), src_cache.data_ptr(), src_cache.numel(), (float)scale,
-                        to_fp8 ? 1 : 0, dt(to_fp8 ? src_cache : dst_cache), stream_of(src_cache)),
+                        (to_fp8 ? 1 : 0) + (kv_cache_dtype == "fp8_e5m2" ? 2 : 0),
+                        dt(to_fp8 ? src_cache : dst_cache), stream_of(src_cache)),
      "convert_fp8");
 }
 

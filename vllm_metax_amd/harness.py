@@ -42,7 +42,7 @@ class ModelConfig:
     group_size: int = 128
     tp: int = 1                 # tensor-parallel degree (heads / ffn sharded, all-reduce after o/down)
     tp_rank: int = 0            # this process's shard
-    kv_cache_dtype: str = "auto"   # "auto" | "fp8" (e4m3 KV cache)
+    kv_cache_dtype: str = "auto"   # "auto" | "fp8" (e4m3 KV cache) | "fp8_e5m2"
 
     @staticmethod
     def llama3_8b(quant="awq", tp=1):
