@@ -785,8 +785,10 @@ def main():
         model = None
         torch.cuda.empty_cache()
         try:
+            from vllm_metax_amd import envs as _envs
+            surface_prepack = bool(_envs.MI355X_PREPACK_WEIGHTS)
             sm = harness.PluginSurfaceModel(make_cfg(args, 1, 0), args.batch, max_len, device=f"cuda:{local_rank}",
-                                            seed=0)
+                                            seed=0, prepack_weights=surface_prepack)
             sm.setup_decode(args.batch, args.input_len, max_len)
             sm.cfg_ctx_for_cost = 0
             sm.mean_decode_len_for_cost = args.input_len + (args.output_len - 1) / 2.0 + 1
@@ -800,8 +802,27 @@ def main():
                        "path": "quant_config.linear.apply_awq/apply_gptq (= torch.ops.vllm._apply_*), "
                                "attention.backend.build_metadata + paged_attention_forward, torch.ops._C.{rms_norm, "
                                "fused_add_rms_norm, rotary_embedding, silu_and_mul}, torch argmax; no operand images, "
-                               "no fused epilogues / prologues, MI355X_PREPACK_WEIGHTS off (the plugin's default)"}
+                               "no fused epilogues / prologues, MI355X_PREPACK_WEIGHTS "
+                               + ("on (the plugin's default: prefill-sized linears multiply by the load-time weight image)"
+                                  if surface_prepack else "off")}
             del sm
+            if quant in ("awq", "gptq"):
+                # ... and with the decoder-layer forwards register_patch() installs under vLLM (patch/fused_layers.py)
+                torch.cuda.empty_cache()
+                sm = harness.PluginSurfaceModel(make_cfg(args, 1, 0), args.batch, max_len,
+                                                device=f"cuda:{local_rank}", seed=0,
+                                                prepack_weights=surface_prepack, patched=True)
+                sm.setup_decode(args.batch, args.input_len, max_len)
+                sm.cfg_ctx_for_cost = 0
+                sm.mean_decode_len_for_cost = args.input_len + (args.output_len - 1) / 2.0 + 1
+                se, stt = timed_jobs(sm, tokens, args, world, barrier, steps=ks, warmup=1)
+                check_outputs(sm, "plugin surface (patched)")
+                surface["with_register_patch"] = {
+                    "value": round(ks * args.batch * args.output_len / se, 2), "ms_per_step": round(se / ks * 1e3, 3),
+                    "ttft_p50_ms": round(statistics.median(stt), 2) if stt else None,
+                    "path": "the same, with the LlamaDecoderLayer / LlamaMLP forwards of vllm_metax_amd/patch "
+                            "(fused_norm_linear, fused_norm_mlp): what register_patch() adds under vLLM"}
+                del sm
         except Exception as ex:  # noqa: BLE001
             surface = {"error": repr(ex)}
 

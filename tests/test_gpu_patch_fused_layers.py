@@ -117,3 +117,31 @@ def test_register_patch_without_vllm_is_a_no_op():
     except ImportError:
         pass
     assert vllm_metax_amd.register_patch() == []
+
+
+def test_plugin_surface_model_patched_equals_plain():
+    """harness.PluginSurfaceModel(patched=True) — the decoder-layer forwards register_patch() installs — serves the
+    same tokens and bit-identical logits as the plain op surface (prefill chunk with images + graph-replayed decode)."""
+    from vllm_metax_amd import harness
+    torch.manual_seed(0)
+    cfg = harness.ModelConfig.llama_geometry("awq", layers=2, vocab=4096)
+    n, plen, steps = 2, 1024, 3
+    tokens = torch.randint(0, cfg.vocab, (n, plen), device="cuda:0")
+    res = []
+    for patched in (False, True):
+        m = harness.PluginSurfaceModel(cfg, n, plen + 16, device="cuda:0", seed=0, prepack_weights=True, patched=patched)
+        m.setup_decode(n, plen, plen + 16)
+        first = m.prefill(tokens, list(range(n)), 0)
+        logits = [m.last_prefill_logits.float().cpu()]
+        m.d_tokens.copy_(first)
+        m.set_decode_lengths(torch.full((n,), plen, device=m.device))
+        toks = [first.cpu()]
+        for _ in range(steps):
+            m.decode_step(use_graph=True)
+            torch.cuda.synchronize()
+            toks.append(m.d_tokens.cpu().clone())
+            logits.append(m.last_logits.float().cpu().clone())
+        res.append((torch.stack(toks), logits))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)

@@ -729,8 +729,13 @@ class PluginSurfaceModel(HotPathModel):
     plain op surface; `patch/fused_layers.py` (register_patch) is what brings the fusions back under vLLM.
     Sampling is torch.argmax + torch index arithmetic, as upstream's sampler / model runner do it."""
 
-    def __init__(self, *a, prepack_weights: bool = False, **kw):
+    def __init__(self, *a, prepack_weights: bool = False, patched: bool = False, **kw):
+        """`patched`: the decoder layer as register_patch() rewires it under vLLM (patch/llama.py ->
+        patch/fused_layers.py: input_layernorm + qkv_proj and post_attention_layernorm + MLP through the fused entry
+        points — operand-image norms, SILU epilogues, image hand-over to down_proj); attention, rotary, cache write and
+        sampling stay the plain ops."""
         super().__init__(*a, **kw)
+        self.patched = patched
         import vllm_metax_amd._C  # noqa: F401  (registers torch.ops._C*)
         from .attention import backend as B
         from .quant_config import linear
@@ -745,7 +750,7 @@ class PluginSurfaceModel(HotPathModel):
             self.k_cache[i], self.v_cache[i] = B.split_kv_cache(self.kv_cache[i], kvh, d)
         self.workspace = B.DecodeWorkspace(self.max_seqs, self.layers[0].q_heads, d, self.max_len, self.dtype,
                                            self.device)
-        # MI355X_PREPACK_WEIGHTS semantics of the plugin (off by default): the image belongs to the layer
+        # MI355X_PREPACK_WEIGHTS semantics of the plugin (on by default since round 3): the image belongs to the layer
         self.images = {}
         if prepack_weights and cfg.quant in ("awq", "gptq"):
             for i, L in enumerate(self.layers):
@@ -765,7 +770,31 @@ class PluginSurfaceModel(HotPathModel):
                                           image=self.images.get((i, name)))
         return q(x)        # fp8 / int8: dynamic activation quant + cutlass_scaled_mm, already plain ops
 
+    def _w4(self, i: int, name: str):
+        from .patch import fused_layers as F
+        q: QLinear = getattr(self.layers[i], name)
+        return F.W4Linear(kind=q.quant, qweight=q.qweight, qzeros=q.qzeros, scales=q.scales, group_size=q.group,
+                          g_idx=getattr(q, "g_idx", None), image=self.images.get((i, name)))
+
+    def _patched_layer(self, i, x, residual, positions, md):
+        """The layer forward register_patch() installs (patch/llama.py), on this model's weights."""
+        from .patch import fused_layers as F
+        L, cfg, C = self.layers[i], self.cfg, torch.ops._C
+        qkv, residual = F.fused_norm_linear(x, residual, L.ln1, cfg.eps, self._w4(i, "qkv"))
+        q, k, v = qkv.split([L.q_size, L.kv_size, L.kv_size], dim=-1)
+        C.rotary_embedding(positions, q, k, cfg.head_dim, self.cos_sin, True)
+        T = q.shape[0]
+        out = torch.empty(T, L.q_heads, cfg.head_dim, dtype=q.dtype, device=q.device)
+        self.B.paged_attention_forward(q.view(T, L.q_heads, cfg.head_dim), k.view(T, L.kv_heads, cfg.head_dim),
+                                       v.view(T, L.kv_heads, cfg.head_dim), self.kv_cache[i], md, out, L.kv_heads,
+                                       self.scale, None, self.kv_dtype, self.k_scale, self.v_scale)
+        o = self._all_reduce(self._apply(i, "o", out.view(T, L.q_size)))
+        mlp, residual = F.fused_norm_mlp(o, residual, L.ln2, cfg.eps, self._w4(i, "gate_up"), self._w4(i, "down"))
+        return self._all_reduce(mlp), residual
+
     def _surface_layer(self, i, x, residual, positions, md):
+        if self.patched and self.cfg.quant in ("awq", "gptq"):
+            return self._patched_layer(i, x, residual, positions, md)
         L, cfg, C = self.layers[i], self.cfg, torch.ops._C
         if residual is None:
             residual = x
