@@ -241,7 +241,7 @@ def instrument(model, timer: EventTimer):
         return 4.0 * S * mean_len * nh * D, nbytes
     wrap("paged_attention_fused_qkv", cost_decode_fused, record_as="paged_attention_v1")
     wrap("rms_norm_image", lambda x, w, eps: (0.0, float(x.numel() * x.element_size() * 2)), record_as="rms_norm")
-    wrap("fused_add_rms_norm_image", lambda x, r, w, eps: (0.0, float(x.numel() * x.element_size() * 5)),
+    wrap("fused_add_rms_norm_image", lambda x, r, w, eps: (0.0, float(x.numel() * x.element_size() * 4)),
          record_as="fused_add_rms_norm")
     wrap("rms_norm_dynamic_per_token_quant",
          lambda out, inp, w, sc, eps, ub=None, res=None:
@@ -263,7 +263,7 @@ def instrument(model, timer: EventTimer):
     wrap("paged_attention_v1",
          lambda out, q, kc, vc, kvh, scale, bt, sl, bs, max_len, *a, **k:
          cost_decode(out, None, None, None, q, kc, vc, kvh, scale, bt, sl, bs, max_len))
-    wrap("fused_add_rms_norm", cost_rows(3, 2))
+    wrap("fused_add_rms_norm", cost_rows(2, 2))             # reads x, residual; writes residual, x (in place)
     wrap("fused_add_rms_norm_slabs", cost_rows(3, 2))       # (+ sk fp32 slabs when sk > 0)
     wrap("qkv_rope_cache", cost_rows(1, 1))
     wrap("rms_norm", cost_rows(1, 1))

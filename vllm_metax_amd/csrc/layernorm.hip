@@ -12,13 +12,18 @@
 //     layernorm_utils.cuh:17-115 — x = float(in) + float(res) is NOT rounded before
 //     the norm; residual = T(x); scale = max(min(absmax,ub)/448, 1/(448*512));
 //     fp8 = sat_e4m3( float(out) / scale )   (true division).
+#include <cstdlib>
+
 #include "common.cuh"
 
 namespace mi355x {
 
 enum NormOut { kOutT = 0, kOutFp8Static = 1, kOutFp8Dynamic = 2 };
 
-template <typename T, int V, int MAXC, bool FUSED_ADD, int OUT>
+// SLABS: the input row is the split-K partial slabs of the preceding GEMM (decode).  A template switch, not a run-time
+// branch: the slab loads keep up to 8 x V values in flight per chunk (64 VGPRs), and as a run-time branch they set the
+// register allocation of the prefill-sized launches too (MAXC = 2: 101 VGPRs = two 512-thread workgroups per CU).
+template <typename T, int V, int MAXC, bool FUSED_ADD, int OUT, bool SLABS = false>
 __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
                                 T* __restrict__ input, int64_t input_stride,
                                 T* __restrict__ residual, const T* __restrict__ weight,
@@ -57,7 +62,7 @@ __global__ void rms_norm_kernel(void* __restrict__ out_v,  // T* or uint8_t*
     if (idx < hidden_size) {
       T iv[V];
       T rv[V];
-      if (slabs != nullptr) {
+      if constexpr (SLABS) {
         // same arithmetic as w4a16_sum_slabs_kernel: fp32 sum in slab order, one rounding to T (fp8 GEMM slabs:
         // times the GEMM's scales first = its finish kernel, common.cuh)
         slab_values<T, V>(slabs + row * hidden_size + idx, sk, slab_stride, slab_scales, row, idx, iv);
@@ -184,16 +189,24 @@ static int launch_norm(void* out, T* input, int64_t input_stride, T* residual,
   // four 16-byte chunks per thread (hidden 8192 at 256 threads) need 128 VGPRs + 9-10 spilled: two chunks at twice
   // the threads fit (101) — Llama-3-70B / Qwen2-72B prefill norms ran at 38 % of the HBM roofline with the spills
   // (profiles/r03_rank_of_8_70b_fp8.json)
-  while (chunks(threads) > (vec ? 2 : maxc) && threads < 1024) threads *= 2;
+  static const int kVecChunks = [] { const char* e = getenv("MI355X_NORM_CHUNKS"); return e ? atoi(e) : 2; }();
+  while (chunks(threads) > (vec ? kVecChunks : maxc) && threads < 1024) threads *= 2;
   if (threads > 1024) threads = 1024;
   MI355X_REQUIRE(chunks(threads) <= maxc, MI355X_EUNSUPPORTED,
                  "%s: hidden_size %d too large (max %d)", name, hidden, maxc * 1024 * (vec ? V : 1));
   const int c = chunks(threads);
   dim3 grid(num_tokens), block(threads);
-#define LAUNCH_NORM(VV, CC)                                                              \
-  hipLaunchKernelGGL((rms_norm_kernel<T, VV, CC, FUSED_ADD, OUT>), grid, block, 0, s, out, \
-                     input, input_stride, residual, weight, scale_in, scales_out,         \
-                     scale_ub, eps, hidden, slabs, sk, slab_stride, slab_scales)
+#define LAUNCH_NORM(VV, CC)                                                                        \
+  do {                                                                                             \
+    if (slabs != nullptr)                                                                          \
+      hipLaunchKernelGGL((rms_norm_kernel<T, VV, CC, FUSED_ADD, OUT, true>), grid, block, 0, s, out, \
+                         input, input_stride, residual, weight, scale_in, scales_out,               \
+                         scale_ub, eps, hidden, slabs, sk, slab_stride, slab_scales);               \
+    else                                                                                           \
+      hipLaunchKernelGGL((rms_norm_kernel<T, VV, CC, FUSED_ADD, OUT, false>), grid, block, 0, s, out, \
+                         input, input_stride, residual, weight, scale_in, scales_out,               \
+                         scale_ub, eps, hidden, slabs, sk, slab_stride, slab_scales);               \
+  } while (0)
   if (vec) {
     if (c <= 1) LAUNCH_NORM(V, 1);
     else if (c <= 2) LAUNCH_NORM(V, 2);
