@@ -31,6 +31,12 @@ def make_prefill_image(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torc
     k = qweight.numel() * 8 // n
     if n % 64 or k % 32 or (k // scales.shape[0]) % 32:
         return None
+    # on by default: never let the image be what exhausts the device (n * k * 2 bytes; keep a 10 % margin of the HBM
+    # free for the KV pool upstream sizes afterwards) — without it the layer simply dequantises per call
+    if qweight.is_cuda:
+        free, total = torch.cuda.mem_get_info(qweight.device)
+        if free - 2 * n * k < total // 10:
+            return None
     return ops.w4a16_prepack(qweight, qzeros, scales, gptq_zeros), n, k
 
 
