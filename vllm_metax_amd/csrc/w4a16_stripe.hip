@@ -40,6 +40,10 @@ namespace mi355x {
 #define STRIPE_DQ 0
 #endif
 // ring depths in stages (-DSTRIPE_WD / -DSTRIPE_AD for experiments)
+// -DSTRIPE_PRIO=1: s_setprio 1 for waves 4-7 before the loop; 2: s_setprio 1 around the dequant + MFMA cluster
+#ifndef STRIPE_PRIO
+#define STRIPE_PRIO 0
+#endif
 #ifndef STRIPE_WD
 #define STRIPE_WD 3
 #endif
@@ -279,6 +283,9 @@ __global__ __launch_bounds__((StripeCfg<MT, NW, SETS, WV>::THREADS)) void w4a16_
 #else
 #define ST_T(x)
 #endif
+#if STRIPE_PRIO == 1
+  if (!w_loader) __builtin_amdgcn_s_setprio(1);   // (experiment: static priority for the later-dispatched half)
+#endif
   for (int it = 0; it < nst; ++it) {
     ST_T(st0);
     const char* ab = smem + Cfg::A_RING + cur_a * Cfg::A_BYTES;
@@ -327,6 +334,9 @@ __global__ __launch_bounds__((StripeCfg<MT, NW, SETS, WV>::THREADS)) void w4a16_
     ST_T(st1);
     __builtin_amdgcn_s_barrier();
     ST_T(st2);
+#if STRIPE_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);                 // (experiment: the computing wave of a SIMD pair first)
+#endif
     __builtin_amdgcn_sched_barrier(0);
     // Software pipeline over the 4*KS_PER_WAVE packed words of the stage: the MFMAs of word j
     // are issued between the dequant VALU of word j+1 (a lone wave issues a VALU op every ~8
@@ -372,6 +382,9 @@ __global__ __launch_bounds__((StripeCfg<MT, NW, SETS, WV>::THREADS)) void w4a16_
     }
     __builtin_amdgcn_sched_barrier(0);
     ST_T(st3);
+#if STRIPE_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 #ifdef STRIPE_STAMP
