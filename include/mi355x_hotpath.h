@@ -520,7 +520,9 @@ int mi355x_paged_prefill_attention_image(
  * qkv row (sk == 0) or its split-K slabs, applies the NeoX rotary to q and k, writes k / v into the cache slot
  * and runs paged_attention_v1 (partition_size 0) or _v2 (partition_size 512 + the reduce launch) on q.
  * Bit-identical to mi355x_qkv_rope_cache + mi355x_paged_attention_v1/_v2 (out and caches; the qkv buffer
- * itself is NOT updated).  Applies to 2-byte dtypes, head_size 128, block_size 16, x 8, 4 or 8 query heads per
+ * itself is NOT updated).  positions == cos_sin_cache == NULL: no rotary — q and k are already rotated (the
+ * attention-backend form: only mi355x_reshape_and_cache of the new tokens is folded into the decode launch).
+ * Applies to 2-byte dtypes, head_size 128, block_size 16, x 8, 4 or 8 query heads per
  * kv head (one workgroup per kv head), scalar_t caches; otherwise returns 1 (no error): run the two calls instead. */
 int mi355x_paged_attention_fused_qkv(
     void* out, float* exp_sums, float* max_logits, void* tmp_out, const void* qkv, int64_t qkv_stride,

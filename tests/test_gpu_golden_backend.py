@@ -181,6 +181,60 @@ def test_backend_mixed_batches(spec):
     assert float(out[T:].abs().max()) == 0.0   # padding rows untouched
 
 
+@pytest.mark.parametrize("spec", [
+    [(1, 40), (1, 32), (1, 1100)],                       # decodes, one 512-token partition exceeded -> v2
+    [(1, 40), (1, 513), (8, 100), (300, 813)],           # mixed: decodes first, then prefills
+    [(1, 700)] * 40,                                     # many (sequence, head) pairs -> v1
+])
+@pytest.mark.parametrize("heads", [(16, 4), (8, 1)])
+def test_backend_folds_the_decode_cache_write_into_the_attention_launch(spec, heads):
+    """q | k | v handed over as the split views of ONE qkv buffer (what upstream's attention layers do): the decode
+    tokens' cache write runs in the prologue of the decode attention launch (fused-qkv form without rotary).  Output
+    and both caches bit-identical to the two-launch path (separate tensors, or the switch off)."""
+    from vllm_metax_amd.attention import backend as B
+    torch.manual_seed(1)
+    H, KVH = heads
+    D, bs, dt = 128, 16, torch.bfloat16
+    q_lens = [s[0] for s in spec]
+    seq_lens = [s[1] for s in spec]
+    R_ = len(spec)
+    max_blocks = (max(seq_lens) + bs - 1) // bs
+    nb = R_ * max_blocks + 2
+    d = dev()
+    bt = torch.randperm(nb)[:R_ * max_blocks].to(torch.int32).reshape(R_, max_blocks)
+    kv0 = (torch.randn(B.kv_cache_shape(nb, bs, KVH, D)) * 0.3).to(dt).to(d)       # arbitrary context
+    T = sum(q_lens)
+    qsl = torch.tensor([0] + list(np.cumsum(q_lens)), dtype=torch.int32)
+    W = (H + 2 * KVH) * D
+    qkv = (torch.randn(T + 3, W + 16) * 0.3).to(dt).to(d)[:, :W]                    # padded rows, strided buffer
+    q3, k3, v3 = (t.view(T + 3, -1, D) for t in qkv.split([H * D, KVH * D, KVH * D], dim=-1))
+    slots = torch.cat([bt[r, (torch.arange(q_lens[r]) + seq_lens[r] - q_lens[r]) // bs].long() * bs
+                       + (torch.arange(q_lens[r]) + seq_lens[r] - q_lens[r]) % bs for r in range(R_)])
+    slt = torch.tensor(seq_lens, dtype=torch.int32)
+    md = B.build_metadata(qsl.to(d), qsl.tolist(), slt.to(d), seq_lens, bt.to(d), slots.to(d), T,
+                          max(q_lens), max(seq_lens), H, D, dt, num_kv_heads=KVH, block_size=bs)
+    assert B._qkv_rows(q3[:md.num_decode_tokens], k3[:md.num_decode_tokens], v3[:md.num_decode_tokens]) is not None
+    res = []
+    for fused in (True, False):
+        B.FUSE_DECODE_CACHE_WRITE = fused
+        try:
+            kvd = kv0.clone()
+            out = torch.zeros(T + 3, H, D, dtype=dt, device=d)
+            B.paged_attention_forward(q3, k3, v3, kvd, md, out, KVH, D ** -0.5)
+            res.append((out, kvd))
+        finally:
+            B.FUSE_DECODE_CACHE_WRITE = True
+    # separate (contiguous) tensors never take the fused form
+    kvd = kv0.clone()
+    out = torch.zeros(T + 3, H, D, dtype=dt, device=d)
+    assert B._qkv_rows(q3.contiguous(), k3.contiguous(), v3.contiguous()) is None
+    B.paged_attention_forward(q3.contiguous(), k3.contiguous(), v3.contiguous(), kvd, md, out, KVH, D ** -0.5)
+    res.append((out, kvd))
+    for o, c in res[1:]:
+        assert_bit_exact(o, res[0][0], "attention output")
+        assert_bit_exact(c, res[0][1], "kv cache")
+
+
 # ----------------------------------------------------------------------------- (3) bindings
 def test_torch_ops_bindings_match_ctypes_path():
     import vllm_metax_amd._C  # noqa: F401

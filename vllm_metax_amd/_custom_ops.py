@@ -880,13 +880,16 @@ def paged_attention_fused_qkv(out: torch.Tensor, exp_sums: Optional[torch.Tensor
     _dev(out, qkv, positions, cos_sin_cache, slot_mapping, key_cache, value_cache, block_tables, seq_lens)
     if qkv.dim() != 2 or qkv.stride(1) != 1 or key_cache.dim() != 5 or value_cache.dim() != 4:
         raise RuntimeError("paged_attention_fused_qkv: qkv [tokens, width], caches in the x-split layout")
-    if positions.dtype != torch.int64 or slot_mapping.dtype != torch.int64:
+    if (positions is None) != (cos_sin_cache is None):
+        raise RuntimeError("paged_attention_fused_qkv: positions and cos_sin_cache go together (both None: no rotary)")
+    if (positions is not None and positions.dtype != torch.int64) or slot_mapping.dtype != torch.int64:
         raise RuntimeError("paged_attention_fused_qkv: positions and slot_mapping must be int64")
     if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
         raise RuntimeError("paged_attention_fused_qkv: block_tables and seq_lens must be int32")
     head_size = key_cache.size(2) * key_cache.size(4)
-    if qkv.dtype not in (torch.bfloat16, torch.float16) or key_cache.dtype != qkv.dtype \
-            or cos_sin_cache.dtype != qkv.dtype or cos_sin_cache.size(-1) != head_size:
+    if qkv.dtype not in (torch.bfloat16, torch.float16) or key_cache.dtype != qkv.dtype:
+        return False
+    if cos_sin_cache is not None and (cos_sin_cache.dtype != qkv.dtype or cos_sin_cache.size(-1) != head_size):
         return False
     n = qkv.size(0)
     if not out.is_contiguous() or out.numel() != n * num_heads * head_size:

@@ -266,6 +266,35 @@ def decode_attention_fused(out: torch.Tensor, exp_sums: torch.Tensor, max_logits
                                          quant_out=quant_out if not use_v1 else None)
 
 
+def _qkv_rows(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor) -> Optional[torch.Tensor]:
+    """[tokens, width] view of the buffer q | k | v are column ranges of (upstream's attention layers hand the backend
+    the three `qkv.split(...)` views of ONE qkv_proj output, rotated in place), or None when they are separate tensors."""
+    try:
+        if query.dim() != 3 or key.dim() != 3 or value.dim() != 3 or query.shape[0] == 0:
+            return None
+        T, H, d = query.shape
+        kvh = key.shape[1]
+        es = query.element_size()
+        if key.shape != (T, kvh, d) or value.shape != (T, kvh, d) or query.dtype != key.dtype or key.dtype != value.dtype:
+            return None
+        w = query.stride(0)
+        if query.stride() != (w, d, 1) or key.stride() != (w, d, 1) or value.stride() != (w, d, 1):
+            return None
+        if w < (H + 2 * kvh) * d or w % 8 or query.data_ptr() % 16:
+            return None
+        if key.data_ptr() != query.data_ptr() + H * d * es or value.data_ptr() != key.data_ptr() + kvh * d * es:
+            return None
+        if query.untyped_storage().data_ptr() != key.untyped_storage().data_ptr() or \
+                key.untyped_storage().data_ptr() != value.untyped_storage().data_ptr():
+            return None
+        return torch.as_strided(query, (T, (H + 2 * kvh) * d), (w, 1), query.storage_offset())
+    except (RuntimeError, AttributeError):
+        return None
+
+
+FUSE_DECODE_CACHE_WRITE = True   # (tests / A-B: False runs reshape_and_cache + decode attention as two launches)
+
+
 def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
                             value: Optional[torch.Tensor], kv_cache: torch.Tensor,
                             md: Mi355xPagedMetadata, output: torch.Tensor, num_kv_heads: int,
@@ -279,16 +308,35 @@ def paged_attention_forward(query: torch.Tensor, key: Optional[torch.Tensor],
     key_cache, value_cache = split_kv_cache(kv_cache, num_kv_heads, head_size)
     block_size = key_cache.shape[3]
     n = md.num_actual_tokens
-    if key is not None and value is not None:
-        # slot_mapping.size(0) is the number of real tokens (cache_kernels.cu:459-469)
-        ops.reshape_and_cache(key, value, key_cache, value_cache, md.slot_mapping[:n], kv_cache_dtype,
-                              k_scale, v_scale)
     nd, ndt = md.num_decodes, md.num_decode_tokens
     if nd > 0 and (sliding_window or softcap):
         # paged_attention_v1/v2 have no such arguments in the reference either (schema
         # csrc/torch_bindings.cpp:45-69); the prefill kernel takes them (flash_attn.py:725-747)
         raise RuntimeError("sliding window / soft-cap are supported on the prefill path only")
-    if nd > 0:
+    # Decode tokens whose q | k | v are the split views of one qkv buffer (what upstream's attention layers pass):
+    # the cache write of the new token runs in the prologue of the decode attention launch
+    # (mi355x_paged_attention_fused_qkv without rotary: q and k are already rotated) — one launch less per layer and
+    # step, bit-identical to reshape_and_cache + paged_attention_v1 / _v2.
+    fused_decode = False
+    if FUSE_DECODE_CACHE_WRITE and nd > 0 and ndt == nd and key is not None and value is not None \
+            and kv_cache_dtype == "auto" and alibi_slopes is None:
+        rows = _qkv_rows(query[:ndt], key[:ndt], value[:ndt])
+        if rows is not None:
+            use_v1 = md.use_v1
+            if use_v1 is None:
+                use_v1 = use_paged_attention_v1(nd, query.shape[1], md.max_decode_seq_len, num_kv_heads, head_size,
+                                                block_size, query.dtype)
+            fused_decode = ops.paged_attention_fused_qkv(
+                output[:ndt], md.exp_sums, md.max_logits, md.tmp_out, rows, None, 0, None, None, md.slot_mapping[:ndt],
+                key_cache, value_cache, query.shape[1], num_kv_heads, scale, md.block_table[:nd], md.seq_lens[:nd],
+                block_size, md.max_decode_seq_len, not use_v1, md.partition_size)
+    if key is not None and value is not None:
+        # slot_mapping.size(0) is the number of real tokens (cache_kernels.cu:459-469)
+        lo = ndt if fused_decode else 0
+        if n > lo:
+            ops.reshape_and_cache(key[lo:n], value[lo:n], key_cache, value_cache, md.slot_mapping[lo:n], kv_cache_dtype,
+                                  k_scale, v_scale)
+    if nd > 0 and not fused_decode:
         decode_attention(output[:ndt], md.exp_sums, md.max_logits, md.tmp_out, query[:ndt],
                          key_cache, value_cache, num_kv_heads, scale, md.block_table[:nd],
                          md.seq_lens[:nd], block_size, md.max_decode_seq_len, alibi_slopes,

@@ -325,9 +325,12 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
     const int embed = D / 2;
     const int cph = embed / XT;
     const int64_t slot = fq.slot_mapping[seq];
-    const T* cos_ptr = static_cast<const T*>(fq.cos_sin_cache) + fq.positions[seq] * D;
+    // (cos_sin_cache == nullptr: q and k arrive already rotated — the backend form, where the model's rotary ran
+    //  before the attention layer: only the cache write of the new token is folded in)
+    const bool rotate = fq.cos_sin_cache != nullptr;
+    const T* cos_ptr = rotate ? static_cast<const T*>(fq.cos_sin_cache) + fq.positions[seq] * D : nullptr;
     Vec16<T> cs0, sn0;
-    if (tid < (GT + 1) * cph) {
+    if (rotate && tid < (GT + 1) * cph) {
       cs0 = load16(cos_ptr + (tid % cph) * XT);
       sn0 = load16(cos_ptr + embed + (tid % cph) * XT);
     }
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
       if (pre0) load_k(0, ka);
       if (pre1) load_k(1, kb);
     }
-    if (tid < (GT + 1) * cph) {     // (GT + 1) * cph <= 40 <= the workgroup size: one chunk pair per thread
+    if (rotate && tid < (GT + 1) * cph) {     // (GT + 1) * cph <= 72 <= the workgroup size: one chunk pair per thread
       const int h = tid / cph;
       const int c = tid - h * cph;
       T* base = q_s + h * D;
@@ -977,8 +980,9 @@ static int fused_qkv_impl(
   if (quant) a.out = out_q;   // (validate_pa wants a non-null output)
   int rc = validate_pa(a, name);
   if (rc != MI355X_OK || num_seqs == 0) return rc;
-  MI355X_REQUIRE(positions && cos_sin_cache && slot_mapping && (sk == 0 || slabs), MI355X_EINVAL,
-                 "%s: null pointer", name);
+  // positions / cos_sin_cache both NULL: no rotary (q and k already rotated; the cache write is all that is folded in)
+  MI355X_REQUIRE(slot_mapping && (sk == 0 || slabs) && ((positions == nullptr) == (cos_sin_cache == nullptr)),
+                 MI355X_EINVAL, "%s: null pointer", name);
   MI355X_REQUIRE(partition_size == 0 || (exp_sums && max_logits && tmp_out), MI355X_EINVAL,
                  "%s: the partitioned form needs exp_sums / max_logits / tmp_out", name);
   MI355X_REQUIRE(partition_size % 16 == 0, MI355X_EINVAL,
