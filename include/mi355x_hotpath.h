@@ -550,9 +550,10 @@ int mi355x_greedy_advance(const void* logits, int64_t logits_stride, int num_seq
  *                       (+ bias[N]).  a_scales: 1 or M floats; b_scales: 1 or N.
  * `workspace` (4-byte elements, 16-byte aligned, may be NULL): M <= 64: sk*m*n elements let the small-M
  * kernel split K across sk <= 8 workgroups (one partial slab [m, n] each, summed in slab order by a finish
- * kernel: no memset, no atomics — deterministic and HIP-graph-replayable; contents are scratch); M >= 1024: >= (roundup(m,16) +
- * roundup(n,16)) * k bytes selects the prefill kernel (operands re-tiled into MFMA operand images,
- * LDS-DMA ring); otherwise the direct kernels run.
+ * kernel: no memset, no atomics — deterministic and HIP-graph-replayable; contents are scratch); M > 320: the prefill
+ * kernel (256 x 256 tiles, LDS-DMA ring).  With k % 128 == 0 and 16-byte aligned rows (lda, ldb, a, b) it reads
+ * both operands in place and needs no workspace; otherwise (k % 64 == 0) >= (roundup(m,16) + roundup(n,16)) * k
+ * bytes let it re-tile the operands into MFMA operand images first; without them the direct kernels run.
  * New capability behind the reference schema cutlass_scaled_mm
  * (csrc/torch_bindings.cpp:251-256; csrc/quantization/cutlass_w8a8/
  *  scaled_mm_entry.cu:34-39,84-140), which the reference only implements for int8. */
@@ -562,12 +563,14 @@ int mi355x_scaled_mm_fp8(void* out, const void* a, const void* b, const float* a
                          int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype,
                          mi355x_stream stream);
 
-/* Load-time weight image of the 8-bit (fp8 / int8) GEMM's packed path (m > 320): mi355x_scaled_mm_* re-tile the
- * weights into 1-KiB operand images on every call (n * k bytes read + written: ~90 us per Llama-3-8B layer);
- * mi355x_scaled_mm_prepack does it once (image: n * k bytes; n % 64 == 0, k % 64 == 0, else returns 1) and
- * mi355x_scaled_mm_prepacked multiplies by the image — bit-identical to the call on b.  workspace: >= roundup(m, 16)
- * * k bytes (the activation image).  Decode-sized calls keep streaming b itself.  (No reference op: the reference's
- * int8 path repacks nothing, cutlass reads b directly.) */
+/* Load-time weight image of the 8-bit (fp8 / int8) GEMM's packed path (m > 320): for int8, and for fp8 with
+ * k % 128 != 0, mi355x_scaled_mm_* re-tile the weights into 1-KiB operand images on every call (n * k bytes read +
+ * written: ~90 us per Llama-3-8B layer); mi355x_scaled_mm_prepack does it once (image: n * k bytes; n % 64 == 0,
+ * k % 64 == 0, else returns 1) and mi355x_scaled_mm_prepacked multiplies by the image — bit-identical to the call on
+ * b.  workspace: >= roundup(m, 16) * k bytes (the activation image).  fp8 operands with k % 128 == 0 and 16-byte
+ * aligned rows need neither: mi355x_scaled_mm_fp8 reads both in place at the image's speed (such weights gain
+ * nothing from an image, and mi355x_scaled_mm_prepacked then takes workspace == NULL).  Decode-sized calls keep
+ * streaming b itself.  (No reference op: the reference's int8 path repacks nothing, cutlass reads b directly.) */
 int mi355x_scaled_mm_prepack(void* image, const void* b, int n, int k, int64_t ldb, mi355x_stream stream);
 int mi355x_scaled_mm_prepacked(void* out, const void* a, const void* b_image, const float* a_scales,
                                int a_scales_numel, const float* b_scales, int b_scales_numel, const void* bias,

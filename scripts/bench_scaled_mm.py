@@ -3,7 +3,9 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_metax_amd import _custom_ops as ops
 d = torch.device("cuda:0")
-Ms = [int(a) for a in sys.argv[1:]] or [64, 8192]
+# --prepacked: the weights as their load-time operand image (scaled_mm_prepack / scaled_mm_prepacked)
+PRE = "--prepacked" in sys.argv
+Ms = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [64, 8192]
 shapes = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096)]
 for kind in ("fp8", "int8"):
     for M in Ms:
@@ -18,14 +20,19 @@ for kind in ("fp8", "int8"):
             a_s = torch.rand(M, 1, device=d) * 1e-2 + 1e-3
             b_s = torch.rand(1, N, device=d) * 1e-2 + 1e-3
             out = torch.empty(M, N, dtype=torch.bfloat16, device=d)
+            img = ops.scaled_mm_prepack(b) if PRE and M > 320 else None
+            if img is not None:
+                call = lambda: ops.scaled_mm_prepacked(out, a, img, N, a_s, b_s, None)
+            else:
+                call = lambda: ops.cutlass_scaled_mm(out, a, b, a_s, b_s, None)
             for _ in range(3):
-                ops.cutlass_scaled_mm(out, a, b, a_s, b_s, None)
+                call()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 10
             e0.record()
             for _ in range(reps):
-                ops.cutlass_scaled_mm(out, a, b, a_s, b_s, None)
+                call()
             e1.record(); torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
             print(f"{kind} M={M:5d} {name:8s}: {us:9.1f} us  {2.0 * M * N * K / us / 1e6:8.1f} T(FL)OP/s  {N * K / us / 1e3:7.0f} GB/s(weights)", flush=True)

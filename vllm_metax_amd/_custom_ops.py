@@ -1200,13 +1200,28 @@ def _scratch_f32(elems: int, device) -> torch.Tensor:
     return _grow(_F32_SCRATCH, device, elems, torch.float32)
 
 
-def scaled_mm_prepack(b: torch.Tensor) -> Optional[torch.Tensor]:
+def _scaled_mm_in_place(a: torch.Tensor, ldb: int, b_ptr: int):
+    """Which operands of the m > 320 8-bit GEMM are read in place, without an operand image (fp8_gemm.hip run_fp8:
+    fp8, k % 128 == 0, rows 16-byte aligned; MI355X_F8_ROWMAJOR bit 0 activations, bit 1 weights, for A/B runs)."""
+    bits = int(os.environ.get("MI355X_F8_ROWMAJOR", "3"))
+    wide = a.dtype == torch.float8_e4m3fn and a.size(1) % 128 == 0
+    a_in_place = wide and bool(bits & 1) and a.stride(0) % 16 == 0 and a.data_ptr() % 16 == 0
+    b_in_place = a_in_place and bool(bits & 2) and ldb % 16 == 0 and b_ptr % 16 == 0
+    return a_in_place, b_in_place
+
+
+def scaled_mm_prepack(b: torch.Tensor, force: bool = False) -> Optional[torch.Tensor]:
     """Load-time operand image of an fp8 / int8 weight `b` [k, n] (column-major, as cutlass_scaled_mm takes it) for
-    the packed path of the 8-bit GEMM (m > 320): uint8 [n * k], or None when the shape has none (n % 64, k % 64)."""
+    the packed path of the 8-bit GEMM (m > 320): uint8 [n * k], or None when the shape has none (n % 64, k % 64) or
+    needs none — fp8 weights with k % 128 == 0 and 16-byte aligned rows are read in place at the image's speed
+    (profiles/r03_fp8_operands_in_place.txt), so no second copy of them is kept unless `force`."""
     _dev(b)
     if b.dim() != 2 or b.stride(0) != 1 or b.dtype not in (torch.float8_e4m3fn, torch.int8):
         raise RuntimeError("scaled_mm_prepack: b must be column-major float8_e4m3fn or int8 [k, n]")
     k, n = b.shape
+    if not force and b.dtype == torch.float8_e4m3fn and k % 128 == 0 and b.stride(1) % 16 == 0 \
+            and b.data_ptr() % 16 == 0 and int(os.environ.get("MI355X_F8_ROWMAJOR", "3")) == 3:
+        return None
     image = torch.empty(n * k, dtype=torch.uint8, device=b.device)
     rc = _abi.load().mi355x_scaled_mm_prepack(_ptr(image), _ptr(b), n, k, b.stride(1), _stream())
     if rc == 1:
@@ -1229,10 +1244,10 @@ def scaled_mm_prepacked(out: torch.Tensor, a: torch.Tensor, b_image: torch.Tenso
         raise RuntimeError("scaled_mm_prepacked: float32 contiguous scales, per-tensor or per-row / per-column")
     if bias is not None and (bias.numel() != n or not bias.is_contiguous() or bias.dtype != out.dtype):
         raise RuntimeError("scaled_mm_prepacked: bad bias")
-    ws = _scratch_f32(((m + 15) // 16 * 16 * k + 3) // 4, a.device)
+    ws = None if _scaled_mm_in_place(a, 0, 0)[0] else _scratch_f32(((m + 15) // 16 * 16 * k + 3) // 4, a.device)
     rc = _abi.load().mi355x_scaled_mm_prepacked(
         _ptr(out), _ptr(a), _ptr(b_image), _ptr(a_scales), a_scales.numel(), _ptr(b_scales), b_scales.numel(),
-        _ptr(bias), _ptr(ws), ws.numel(), m, n, k, a.stride(0), out.stride(0), _dt(out),
+        _ptr(bias), _ptr(ws), ws.numel() if ws is not None else 0, m, n, k, a.stride(0), out.stride(0), _dt(out),
         1 if a.dtype == torch.int8 else 0, _stream())
     _abi.check(rc, "scaled_mm_prepacked")
 
@@ -1303,9 +1318,11 @@ def cutlass_scaled_mm(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
     if m <= 320:       # (64 < m <= 320: passes of 64 rows through the decode kernel, one pass's slabs at a time)
         ws = torch.empty((8, min(m, 64), n), dtype=torch.float32, device=a.device)
     elif m >= int(os.environ.get("MI355X_F8_PACKED_MIN_M", "321")) and k % 64 == 0:
-        # prefill: scratch for the re-tiled operands, (roundup(m,16) + roundup(n,16)) * k bytes
-        need = ((m + 15) // 16 * 16 + (n + 15) // 16 * 16) * k
-        ws = _scratch_f32((need + 3) // 4, a.device)
+        # prefill: scratch for the re-tiled operands, (roundup(m,16) + roundup(n,16)) * k bytes — none for the operands
+        # the GEMM reads in place
+        a_in_place, b_in_place = _scaled_mm_in_place(a, b.stride(1), b.data_ptr())
+        need = (0 if a_in_place else (m + 15) // 16 * 16 * k) + (0 if b_in_place else (n + 15) // 16 * 16 * k)
+        ws = _scratch_f32((need + 3) // 4, a.device) if need else None
     else:
         ws = None
     fn = _abi.load().mi355x_scaled_mm_int8 if a.dtype == torch.int8 else _abi.load().mi355x_scaled_mm_fp8

@@ -517,12 +517,19 @@ __global__ __launch_bounds__(256) void gemm8_decode_kernel(
 // adjacent pieces form the 32-byte operands of one 16x16x128 MFMA (Op::run32).
 // IL: B was packed with interleaved rows (n % 64 == 0): a lane owns 4 adjacent output columns and
 // stores them as one 8-byte word; otherwise lane lc = one column per 16-column tile.
-template <typename T, typename Op, int P, bool IL>
+// AROW / BROW (P = 2 only): the operand is NOT an image but the row-major byte matrix itself (leading dimension
+// lda / ldb, 16-byte aligned rows) — no pack launch, no load-time weight image.  The LDS-DMA copies build the LDS image
+// on the fly with per-lane source addresses: a wave-instruction = 8 rows x 128 bytes (whole cache lines: both 64-k
+// slices of the stage; 16 rows x 64 bytes, half a line per request, cost the chunked-prefill job 4 % whenever the
+// activations were not L2-hot, profiles/r03_fp8_operands_in_place.txt), slot 8 (row & 7) + (chunk ^ (row & 6)) with
+// chunk = 4 slice + lr — the rotation keeps the ds_read_b128 lane groups ({0-3, 12-15, 20-27}, ...) on 16 distinct
+// 16-byte bank groups; rows 0-7 / 8-15 of a tile sit where the image form keeps its two slices.
+template <typename T, typename Op, int P, bool IL, bool AROW = false, bool BROW = false>
 __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
     T* __restrict__ out, const uint4* __restrict__ pa, const uint4* __restrict__ pb,
     const float* __restrict__ a_scales, int a_per_row, const float* __restrict__ b_scales,
     int b_per_col, const T* __restrict__ bias, int m, int n, int k, int64_t ldc, int num_m_blocks,
-    int num_tiles) {
+    int num_tiles, int64_t lda = 0, int64_t ldb = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
   constexpr int S = P == 1 ? 4 : 2;       // ring depth
@@ -554,19 +561,47 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
   const int kpieces = k / 64;       // pieces along K
   const int kstages = kpieces / P;
 
-  const uint4* a_src[2];
-  const uint4* b_src[2];
+  static_assert(P == 2 || !(AROW || BROW), "operands in place: the two-slice stage only");
+  // [i][j]: row tile i of this wave; j = k slice of the stage (image) or row half 0-7 / 8-15 (row-major)
+  const uint4* a_src[2][P];
+  const uint4* b_src[2][P];
+  // row-major operands: lane -> (row of the half tile, 16-byte chunk of the stage's 128 k bytes)
+  const int rm_row = lane >> 3, rm_chunk = (lane & 7) ^ ((lane >> 3) & 6);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int p = wave * 2 + i;
-    int gmt = mb * 16 + p;
-    const int max_mt = ((m + 15) >> 4) - 1;
-    gmt = gmt < max_mt ? gmt : max_mt;
-    a_src[i] = pa + (int64_t)gmt * kpieces * 64 + lane;
-    int gnt = nb * 16 + p;
-    const int max_nt = ((n + 15) >> 4) - 1;
-    gnt = gnt < max_nt ? gnt : max_nt;
-    b_src[i] = pb + (int64_t)gnt * kpieces * 64 + lane;
+    if constexpr (AROW) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        int row = mb * 256 + p * 16 + 8 * j + rm_row;
+        row = row < m ? row : m - 1;          // rows >= m only feed accumulator rows that are never stored
+        a_src[i][j] =
+            reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(pa) + (int64_t)row * lda) + rm_chunk;
+      }
+    } else {
+      int gmt = mb * 16 + p;
+      const int max_mt = ((m + 15) >> 4) - 1;
+      gmt = gmt < max_mt ? gmt : max_mt;
+#pragma unroll
+      for (int j = 0; j < P; ++j) a_src[i][j] = pa + ((int64_t)gmt * kpieces + j) * 64 + lane;
+    }
+    if constexpr (BROW) {
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        // IL: piece 4 G + t holds columns 64 G + 4 r + t (what pack_a_kernel's interleave does)
+        const int r = 8 * j + rm_row;
+        int col = nb * 256 + (IL ? 64 * (p >> 2) + 4 * r + (p & 3) : p * 16 + r);
+        col = col < n ? col : n - 1;
+        b_src[i][j] =
+            reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(pb) + (int64_t)col * ldb) + rm_chunk;
+      }
+    } else {
+      int gnt = nb * 16 + p;
+      const int max_nt = ((n + 15) >> 4) - 1;
+      gnt = gnt < max_nt ? gnt : max_nt;
+#pragma unroll
+      for (int j = 0; j < P; ++j) b_src[i][j] = pb + ((int64_t)gnt * kpieces + j) * 64 + lane;
+    }
   }
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
   auto stage = [&](int buf, int ks) {
@@ -575,10 +610,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int p = wave * 2 + i;
-        const int64_t src = (int64_t)(ks * P + pp) * 64;
+        // a stage advances an image by P pieces of 64 slots, a row by P x 64 bytes = 4 P uint4
         const int dst = buf * kStage + pp * kPiece + p * 64;
-        lds_dma16(a_src[i] + src, lds_base + dst * 16);
-        lds_dma16(b_src[i] + src, lds_base + (dst + kBOff) * 16);
+        lds_dma16(a_src[i][pp] + (int64_t)ks * (AROW ? 4 * P : 64 * P), lds_base + dst * 16);
+        lds_dma16(b_src[i][pp] + (int64_t)ks * (BROW ? 4 * P : 64 * P), lds_base + (dst + kBOff) * 16);
       }
     }
   };
@@ -593,6 +628,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
     if (s2 < kstages) stage(s2, s2);
   }
   const int frag = frag_swz(lr, lc);
+  // P = 2: where a lane finds its 16 bytes of k slice 0 / 1 inside the tile's two KiB
+  const int rm2 = (lc >> 3) * kPiece + 8 * (lc & 7) + (lr ^ (lc & 6));
+  const int frag_a0 = AROW ? rm2 : frag, frag_a1 = AROW ? (rm2 ^ 4) : kPiece + frag;
+  const int frag_b0 = BROW ? rm2 : frag, frag_b1 = BROW ? (rm2 ^ 4) : kPiece + frag;
   int cur = 0;
   if constexpr (P == 1) {
     // ping-pong of the two waves of a SIMD, as in gemm_packed_kernel (w4a16_unfused.hip): waves 4-7 enter
@@ -652,21 +691,21 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
         slot = slot >= S ? slot - S : slot;
         if (nxt < kstages) stage(slot, nxt);
       }
-      const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
-      const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
+      const uint4* abuf = lds + cur * kStage + (wm * 8) * 64;
+      const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64;
       uint4 bf[4][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        bf[t][0] = bbuf[t * 64];
-        bf[t][1] = bbuf[kPiece + t * 64];
+        bf[t][0] = bbuf[t * 64 + frag_b0];
+        bf[t][1] = bbuf[t * 64 + frag_b1];
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         uint4 af[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          af[i][0] = abuf[(4 * h + i) * 64];
-          af[i][1] = abuf[kPiece + (4 * h + i) * 64];
+          af[i][0] = abuf[(4 * h + i) * 64 + frag_a0];
+          af[i][1] = abuf[(4 * h + i) * 64 + frag_a1];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -882,6 +921,11 @@ static int run_decode(const Fp8Args& g, int a_per_row, int b_per_col) {
 #undef DEC_NT
 }
 
+static int f8_rowmajor_bits() {
+  static const int bits = [] { const char* e = getenv("MI355X_F8_ROWMAJOR"); return e ? atoi(e) : 3; }();
+  return bits;
+}
+
 template <typename T, typename Op>
 static int run_fp8(const Fp8Args& g) {
   const int a_per_row = g.a_scales_numel > 1;
@@ -891,24 +935,38 @@ static int run_fp8(const Fp8Args& g) {
   {
     // prefill: both operands re-tiled into operand images, then the LDS-DMA ring kernel
     const int64_t m_pad = ((int64_t)g.m + 15) / 16 * 16, n_pad = ((int64_t)g.n + 15) / 16 * 16;
-    const int64_t need = (m_pad + (g.b_image ? 0 : n_pad)) * g.k;   // bytes
+    // fp8, K % 128 == 0 (the two-slice stage): operands with 16-byte aligned rows are read in place — no pack launch,
+    // and weights without a load-time image cost nothing extra (Llama-3-8B layer at M = 576 / 1024 / 4096 / 8192:
+    // 396 / 409 / 855 / 1541 us with both images -> 374 / 383 / 798 / 1452 with the activations in place, 374 / 380 /
+    // 808 / 1466 with both in place).  MI355X_F8_ROWMAJOR (bit 0: activations, bit 1: weights) for A/B runs.
+    const int kRowMajor = f8_rowmajor_bits();
+    bool wide = false;
+    if constexpr (Op::kWide) wide = g.k % 128 == 0;
+    const bool arow = wide && (kRowMajor & 1) && g.lda % 16 == 0 && (reinterpret_cast<uintptr_t>(g.a) & 15) == 0;
+    const bool brow = arow && (kRowMajor & 2) && !g.b_image && g.ldb % 16 == 0 &&
+                      (reinterpret_cast<uintptr_t>(g.b) & 15) == 0;
+    const int64_t need = (arow ? 0 : m_pad * g.k) + (g.b_image || brow ? 0 : n_pad * g.k);   // bytes
     // 320 < M < 1024 too since round 3 (was the direct-load tile kernel: Llama-3-8B layer at M = 384 / 512 / 768
     // 660 / 672 / 772 -> 409 / 422 / 470 us, profiles/r03_scaled_mm_mid_m.txt); MI355X_F8_PACKED_MIN_M for A/B runs
     static const int kPackedMinM = [] { const char* e = getenv("MI355X_F8_PACKED_MIN_M"); return e ? atoi(e) : 321; }();
-    if (g.m >= kPackedMinM && g.ws != nullptr && g.ws_elems * 4 >= need && g.k % 64 == 0 &&
-        (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0) {
-      bf16_t* pa = reinterpret_cast<bf16_t*>(g.ws);
-      const bf16_t* pb = g.b_image ? static_cast<const bf16_t*>(g.b_image) : pa + m_pad * g.k / 2;
+    if (g.m >= kPackedMinM && (need == 0 || (g.ws != nullptr && g.ws_elems * 4 >= need &&
+                                             (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0)) &&
+        g.k % 64 == 0) {
+      bf16_t* ws16 = reinterpret_cast<bf16_t*>(g.ws);
+      const void* pa = arow ? g.a : static_cast<const void*>(ws16);
+      bf16_t* pb_ws = arow ? ws16 : ws16 + m_pad * g.k / 2;
+      const void* pb = g.b_image ? g.b_image : (brow ? g.b : static_cast<const void*>(pb_ws));
       // 4 adjacent output columns per lane (8-byte stores) when the shape allows it (a prepacked image is always
       // interleaved: its entry point checked the same conditions)
       const bool il = g.n % 64 == 0 && g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0;
       const int k2 = g.k / 2;   // the byte matrices viewed as 2-byte elements
-      hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, (int)(m_pad / 16)),
-                         dim3(256), 0, g.stream, pa, reinterpret_cast<const bf16_t*>(g.a), g.m, k2,
-                         g.lda / 2);
-      if (!g.b_image)
+      if (!arow)
+        hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, (int)(m_pad / 16)),
+                           dim3(256), 0, g.stream, ws16, reinterpret_cast<const bf16_t*>(g.a), g.m, k2,
+                           g.lda / 2);
+      if (!g.b_image && !brow)
         hipLaunchKernelGGL(pack_a_kernel<bf16_t>, dim3((k2 + kPackK - 1) / kPackK, (int)(n_pad / 16)),
-                           dim3(256), 0, g.stream, pa + m_pad * g.k / 2, reinterpret_cast<const bf16_t*>(g.b), g.n, k2,
+                           dim3(256), 0, g.stream, pb_ws, reinterpret_cast<const bf16_t*>(g.b), g.n, k2,
                            g.ldb / 2, il ? 1 : 0);
       int rc = check_launch("scaled_mm(pack)");
       if (rc) return rc;
@@ -930,16 +988,18 @@ static int run_fp8(const Fp8Args& g) {
         hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(512), smem, g.stream, out,
                            reinterpret_cast<const uint4*>(pa), reinterpret_cast<const uint4*>(pb),
                            g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.k, g.ldc,
-                           num_m_blocks, num_tiles);
+                           num_m_blocks, num_tiles, g.lda, g.ldb);
         return 0;
       };
-      static PerDeviceOnce attr[4];   // per kernel variant, one bit per device
-      bool wide = false;
-      if constexpr (Op::kWide) wide = g.k % 128 == 0;
+      static PerDeviceOnce attr[8];   // per kernel variant, one bit per device
       if constexpr (Op::kWide) {
         if (wide) {
-          rc = il ? launch(gemm8_packed_kernel<T, Op, 2, true>, attr[3])
-                  : launch(gemm8_packed_kernel<T, Op, 2, false>, attr[2]);
+          if (brow) rc = il ? launch(gemm8_packed_kernel<T, Op, 2, true, true, true>, attr[7])
+                            : launch(gemm8_packed_kernel<T, Op, 2, false, true, true>, attr[6]);
+          else if (arow) rc = il ? launch(gemm8_packed_kernel<T, Op, 2, true, true, false>, attr[5])
+                                 : launch(gemm8_packed_kernel<T, Op, 2, false, true, false>, attr[4]);
+          else rc = il ? launch(gemm8_packed_kernel<T, Op, 2, true>, attr[3])
+                       : launch(gemm8_packed_kernel<T, Op, 2, false>, attr[2]);
         }
       }
       if (!wide) {
@@ -1067,8 +1127,8 @@ extern "C" int mi355x_scaled_mm_prepack(void* image, const void* b, int n, int k
 }
 
 // cutlass_scaled_mm with the weights given as that image (m > 320, the packed path; workspace: >= roundup(m, 16) * k
-// bytes for the activation image).  is_int8: the int8 arithmetic of mi355x_scaled_mm_int8.  Bit-identical to the
-// call on `b` itself.
+// bytes for the activation image — may be NULL for fp8 with k % 128 == 0, whose activations are read in place).
+// is_int8: the int8 arithmetic of mi355x_scaled_mm_int8.  Bit-identical to the call on `b` itself.
 extern "C" int mi355x_scaled_mm_prepacked(void* out, const void* a, const void* b_image,
                                           const float* a_scales, int a_scales_numel,
                                           const float* b_scales, int b_scales_numel, const void* bias,
@@ -1080,13 +1140,14 @@ extern "C" int mi355x_scaled_mm_prepacked(void* out, const void* a, const void* 
   MI355X_REQUIRE(lda % 16 == 0 && ldc % 4 == 0, MI355X_EUNSUPPORTED, "scaled_mm_prepacked: lda %% 16, ldc %% 4");
   MI355X_REQUIRE((a_scales_numel == 1 || a_scales_numel == m) && (b_scales_numel == 1 || b_scales_numel == n),
                  MI355X_EINVAL, "scaled_mm_prepacked: scales must be per-tensor or per-row / per-column");
-  MI355X_REQUIRE(out && a && b_image && a_scales && b_scales && workspace, MI355X_EINVAL,
-                 "scaled_mm_prepacked: null pointer");
+  MI355X_REQUIRE(out && a && b_image && a_scales && b_scales, MI355X_EINVAL, "scaled_mm_prepacked: null pointer");
   MI355X_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b_image) |
                    reinterpret_cast<uintptr_t>(workspace)) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0,
                  MI355X_EUNSUPPORTED, "scaled_mm_prepacked: alignment");
   const int64_t m_pad = ((int64_t)m + 15) / 16 * 16;
-  MI355X_REQUIRE(workspace_elems * 4 >= m_pad * k, MI355X_EINVAL, "scaled_mm_prepacked: workspace too small");
+  const bool a_in_place = !is_int8 && k % 128 == 0 && (f8_rowmajor_bits() & 1);
+  MI355X_REQUIRE(a_in_place || (workspace && workspace_elems * 4 >= m_pad * k), MI355X_EINVAL,
+                 "scaled_mm_prepacked: workspace too small");
   Fp8Args g{out, static_cast<const uint8_t*>(a), nullptr, a_scales, a_scales_numel, b_scales, b_scales_numel, bias,
             m, n, k, lda, 0, ldc, workspace, workspace_elems, static_cast<hipStream_t>(stream)};
   g.b_image = b_image;

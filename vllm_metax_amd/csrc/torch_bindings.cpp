@@ -431,8 +431,18 @@ void cutlass_scaled_mm(Tensor& out, const Tensor& a, const Tensor& b, const Tens
   Tensor ws;  // small-M (decode) shapes split K across up to 8 workgroups, one 4-byte partial slab [m, n] each
   // (64 < m <= 320: passes of 64 rows through the decode kernel; above: the packed-image kernel)
   if (m <= 320 && m > 0) ws = at::empty({8, m < 64 ? m : 64, n}, a.options().dtype(at::kFloat));
-  else if (m > 320 && k % 64 == 0)   // scratch for the re-tiled operands (bytes / 4)
-    ws = at::empty({(((m + 15) / 16 * 16 + (n + 15) / 16 * 16) * k + 3) / 4}, a.options().dtype(at::kFloat));
+  else if (m > 320 && k % 64 == 0) {
+    // scratch for the re-tiled operands (bytes / 4) — none for the operands the GEMM reads in place (fp8_gemm.hip
+    // run_fp8: fp8, k % 128 == 0, 16-byte aligned rows; MI355X_F8_ROWMAJOR for A/B runs)
+    const char* e = getenv("MI355X_F8_ROWMAJOR");
+    const int bits = e ? atoi(e) : 3;
+    const bool wide = !is_i8 && k % 128 == 0;
+    const bool a_in_place = wide && (bits & 1) && a.stride(0) % 16 == 0 && reinterpret_cast<uintptr_t>(a.data_ptr()) % 16 == 0;
+    const bool b_in_place = a_in_place && (bits & 2) && b.stride(1) % 16 == 0 &&
+                            reinterpret_cast<uintptr_t>(b.data_ptr()) % 16 == 0;
+    const int64_t need = (a_in_place ? 0 : (m + 15) / 16 * 16 * k) + (b_in_place ? 0 : (n + 15) / 16 * 16 * k);
+    if (need) ws = at::empty({(need + 3) / 4}, a.options().dtype(at::kFloat));
+  }
   auto fn = is_i8 ? mi355x_scaled_mm_int8 : mi355x_scaled_mm_fp8;   // scaled_mm_entry.cu:34-39 / new
   ok(fn(out.data_ptr(), a.data_ptr(), b.data_ptr(), a_scales.data_ptr<float>(), a_scales.numel(),
         b_scales.data_ptr<float>(), b_scales.numel(),

@@ -203,9 +203,10 @@ class QLinear:
         return torch.matmul(x, self.weight)
 
     def _scaled_mm(self, out, xq, xs):
-        """cutlass_scaled_mm on this layer's 8-bit weights; prefill-sized calls (m > 320) multiply by the weights'
-        operand image built once at first use (mi355x_scaled_mm_prepack: n * k more bytes per layer, the per-call
-        re-tiling of the weights gone) — MI355X_PREPACK=0 or a shape without an image: the plain op."""
+        """cutlass_scaled_mm on this layer's 8-bit weights; prefill-sized calls (m > 320) on weights the GEMM re-tiles
+        per call (int8; fp8 with k % 128 != 0) multiply by the weights' operand image built once at first use
+        (mi355x_scaled_mm_prepack: n * k more bytes per layer) — MI355X_PREPACK=0, a shape without an image or fp8
+        weights read in place (scaled_mm_prepack returns None): the plain op."""
         if xq.shape[0] > 320 and self.prepack and hasattr(ops, "scaled_mm_prepack"):
             if getattr(self, "_w8_image", None) is None:
                 img = ops.scaled_mm_prepack(self.weight)
