@@ -360,10 +360,9 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
 // — 64 x 64 tile, K waves strided by 4, no prefetch — ran the four Llama-3-70B per-rank projections at 28 us per
 // launch, 0.95 TB/s; it stays as the fallback for K % 128 != 0.)
 //   * a workgroup = 4 waves = 4 x NT column tiles of 16 and ONE contiguous K range of `steps` x 128 bytes; the
-//     activation rows of that range (64 x R bytes, an L2-resident re-read) are copied ONCE by LDS-DMA into the
-//     MFMA operand image (per-lane source addresses build the image on the fly: piece (k-step, half, row tile) =
-//     1 KiB, lane (lr, lc) <- row lc, bytes 64 half + 16 lr), one barrier, and from then on the waves run free:
-//     no barrier, no shared ring in the loop.
+//     activation rows of that range (64 x R bytes, an L2-resident re-read) are copied ONCE by LDS-DMA into LDS
+//     (per-lane source addresses, 8 rows x 128 bytes = whole cache lines per copy), one barrier, and from then on
+//     the waves run free: no barrier, no shared ring in the loop.
 //   * weights go HBM -> VGPR directly (a weight byte is used by exactly one wave; LDS would only add a hop), three
 //     register buffers deep: the loads of k-step kk+2 are issued before the MFMAs of kk (8 KiB per wave and k-step
 //     at NT = 4, 16 KiB in flight per wave), addresses of the tail clamped instead of branched so that the
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(256) void gemm8_decode_kernel(
   // NT is: a CU needs >= ~48 KiB in flight to keep its share of the HBM stream (latency ~2 us under load)
   constexpr int D = 12 / NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const uint4* a_img = reinterpret_cast<const uint4*>(smem);   // [k-step][half][row tile][64 lanes]
+  const uint4* a_img = reinterpret_cast<const uint4*>(smem);   // [k-step][row tile][row half][64 slots]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lc = lane & 15, lr = lane >> 4;
@@ -416,15 +415,19 @@ __global__ __launch_bounds__(256) void gemm8_decode_kernel(
   };
 #pragma unroll
   for (int s = 0; s < D - 1; ++s) load_b(s, bq[s]);
-  // activation image of this K range: piece q = (kk * 2 + half) * MT + i, dealt round-robin to the 4 waves
+  // activation image of this K range: copy q = (kk * MT + i) * 2 + j = rows 8 j .. 8 j + 7 of row tile i, the 128 bytes
+  // of k-step kk — whole cache lines (lane -> row l >> 3, chunk (l & 7) ^ (row & 6): the rotation that keeps the
+  // fragment reads below off each other's banks, as in gemm8_packed_kernel's AROW form; the 16 rows x 64 bytes copies
+  // of the first version sent 64 separate 16-byte requests per instruction); dealt round-robin to the 4 waves
   {
     const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const int pieces = nk * 2 * MT;
-    for (int q = wave; q < pieces; q += 4) {
-      const int i = q % MT, kh = q / MT;
-      int row = 16 * i + lc;
+    const int copies = nk * 2 * MT;
+    const int rm_row = lane >> 3, rm_chunk = (lane & 7) ^ ((lane >> 3) & 6);
+    for (int q = wave; q < copies; q += 4) {
+      const int j = q & 1, i = (q >> 1) % MT, kk = (q >> 1) / MT;
+      int row = 16 * i + 8 * j + rm_row;
       row = row < m ? row : m - 1;           // rows >= m only feed accumulator rows that are never stored
-      lds_dma16(a + (int64_t)row * lda + (int64_t)kt0 * 128 + kh * 64 + 16 * lr, lds_base + q * 1024);
+      lds_dma16(a + (int64_t)row * lda + (int64_t)(kt0 + kk) * 128 + 16 * rm_chunk, lds_base + q * 1024);
     }
     lds_dma_wait<0>();
   }
@@ -436,11 +439,13 @@ __global__ __launch_bounds__(256) void gemm8_decode_kernel(
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = typename Op::acc_t{0, 0, 0, 0};
   }
+  // lane (lr, lc) of row tile i: row lc's bytes 16 lr .. (k slice 0) and 64 + 16 lr .. (slice 1) of the k-step
+  const int a_frag = (lc >> 3) * 64 + 8 * (lc & 7) + (lr ^ (lc & 6));
   auto mma = [&](int kk, uint4 (&cur)[NT][2]) {
-    const uint4* ap = a_img + (kk * 2 * MT) * 64 + lane;
+    const uint4* ap = a_img + (kk * MT) * 128;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const uint4 a0 = ap[i * 64], a1 = ap[(MT + i) * 64];
+      const uint4 a0 = ap[i * 128 + a_frag], a1 = ap[i * 128 + (a_frag ^ 4)];
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[i][t] = Op::run32(a0, a1, cur[t][0], cur[t][1], acc[i][t]);
     }
