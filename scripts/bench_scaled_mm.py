@@ -7,7 +7,10 @@ d = torch.device("cuda:0")
 PRE = "--prepacked" in sys.argv
 Ms = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [64, 8192]
 shapes = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096)]
-for kind in ("fp8", "int8"):
+if "--70b-rank" in sys.argv:     # one TP = 8 rank of Llama-3-70B
+    shapes = [("qkv", 8192, 1280), ("o", 1024, 8192), ("gate_up", 8192, 7168), ("down", 3584, 8192)]
+KINDS = ("fp8",) if "--fp8" in sys.argv else ("fp8", "int8")
+for kind in KINDS:
     for M in Ms:
         tot = 0.0
         for name, K, N in shapes:

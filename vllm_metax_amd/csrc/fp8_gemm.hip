@@ -363,7 +363,11 @@ __global__ __launch_bounds__(256) void fp8_gemm_small_kernel(
 //     activation rows of that range (64 x R bytes, an L2-resident re-read) are copied ONCE by LDS-DMA into LDS
 //     (per-lane source addresses, 8 rows x 128 bytes = whole cache lines per copy), one barrier, and from then on
 //     the waves run free: no barrier, no shared ring in the loop.
-//   * weights go HBM -> VGPR directly (a weight byte is used by exactly one wave; LDS would only add a hop), three
+//   * weights go HBM -> VGPR directly (a weight byte is used by exactly one wave; LDS would only add a hop — but in
+//     the MFMA's B layout the 4 lanes of a quad sit on 4 different weight rows, 64 requests of 16 bytes per
+//     instruction: a timing-only build with quads on 64-byte runs (wrong lanes) ran the 70B rank layer in 51.2
+//     instead of 56.4 us, profiles/r03_fp8_decode_whole_line_copies.txt — the bound on what a wave-private LDS ring
+//     for the weights could gain, which would have to come out of the activation image's LDS), three
 //     register buffers deep: the loads of k-step kk+2 are issued before the MFMAs of kk (8 KiB per wave and k-step
 //     at NT = 4, 16 KiB in flight per wave), addresses of the tail clamped instead of branched so that the
 //     compiler's wait-count pass keeps counted vmcnt waits.
