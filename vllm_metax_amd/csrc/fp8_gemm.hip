@@ -71,6 +71,9 @@ struct OpFp8 {
   }
 };
 struct OpI8 {
+  // (int8 through the two-slice stage with both operands in place — two 16x16x64 per operand pair — was measured
+  //  SLOWER than its 4-stage ping-pong ring on images: 383 -> 415 us per call at M = 8192, 78 -> 94 at M = 576,
+  //  profiles/r03_fp8_operands_in_place.txt)
   static constexpr bool kWide = false;
   typedef i32x4_t acc_t;
   typedef int elem_t;

@@ -377,7 +377,10 @@ __global__ __launch_bounds__(kPaMaxThreads) void paged_attention_kernel(
       for (int c = tid; c < CQ; c += nthreads) store16(kw + (c * BS + t) * XT, load16(q_s + GT * D + c * XT));
       for (int d = tid; d < D; d += nthreads) vw[(int64_t)d * BS + t] = q_s[(GT + 1) * D + d];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the stores are complete before the barrier below
+    // the stores are complete before the barrier below (its vmcnt(0) also drains the prefetched K blocks: a
+    // timing-only build without the fence ran the in-job launch in 54.0-54.5 us against 54.4-54.6 — nothing to gain,
+    // profiles/r03_attn_fq_nofence.txt)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   } else {
   // ---- stage q (packed scalar_t) into LDS; absent heads are zero ---------------
   for (int i = tid; i < GT * CQ; i += nthreads) {
