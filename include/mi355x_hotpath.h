@@ -563,6 +563,12 @@ int mi355x_scaled_mm_fp8(void* out, const void* a, const void* b, const float* a
                          int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int out_dtype,
                          mi355x_stream stream);
 
+/* Shapes with few 256 x 256 output tiles (chunked-prefill sized m, the narrow n of a TP shard) split K inside the
+ * m > 320 kernel when the workspace has room for the partial tiles: mi355x_scaled_mm_split_elems returns the 4-byte
+ * elements to ADD to the operand-image scratch above for that (0: this shape is not split).  Without them the GEMM
+ * runs unsplit — same bits for int8, fp32 summation order differs for fp8 (deterministic either way). */
+int64_t mi355x_scaled_mm_split_elems(int m, int n, int k);
+
 /* Load-time weight image of the 8-bit (fp8 / int8) GEMM's packed path (m > 320): for int8, and for fp8 with
  * k % 128 != 0, mi355x_scaled_mm_* re-tile the weights into 1-KiB operand images on every call (n * k bytes read +
  * written: ~90 us per Llama-3-8B layer); mi355x_scaled_mm_prepack does it once (image: n * k bytes; n % 64 == 0,

@@ -274,6 +274,39 @@ def test_scaled_mm_fp8_in_place_strided_operands(m, n, k):
     assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("kind", ["fp8", "int8"])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("m,n,k", [(576, 4096, 4096), (576, 4096, 14336), (2048, 1280, 8192), (700, 1008, 2048),
+                                   (333, 320, 1152)])
+def test_scaled_mm_prefill_kernel_split_k(kind, m, n, k, bias):
+    """m > 320 with few 256 x 256 tiles (chunked-prefill sized m, a TP shard's narrow n): the prefill kernel splits K
+    through partial slabs + the finish kernel (mi355x_scaled_mm_split_elems > 0 for these shapes).  fp8: the oracle
+    within the GEMM tolerance; int8: exact (int32 partial sums).  (700, 1008, 2048): ragged rows and columns, the
+    one-column-per-lane epilogue; (333, 320, 1152): 9 k-steps over 2 splits, an uneven K range."""
+    from vllm_metax_amd import _abi
+    assert _abi.load().mi355x_scaled_mm_split_elems(m, n, k) >= 2 * m * n
+    d = dev()
+    if kind == "fp8":
+        a, b, a_s, b_s, bi = _mk(m, n, k, True, True, bias, torch.bfloat16, seed=k)
+        ref = R.scaled_mm_fp8(a, b, a_s, b_s, torch.bfloat16, bi)
+        bd = b.t().contiguous().to(d).t()
+    else:
+        g = torch.Generator().manual_seed(k + m)
+        a = torch.randint(-127, 128, (m, k), generator=g, dtype=torch.int32).to(torch.int8)
+        b_nk = torch.randint(-127, 128, (n, k), generator=g, dtype=torch.int32).to(torch.int8)
+        a_s = torch.rand(m, 1, generator=g) * 1e-2 + 1e-3
+        b_s = torch.rand(1, n, generator=g) * 1e-2 + 1e-3
+        bi = (torch.randn(n, generator=g) * 0.5).to(torch.bfloat16) if bias else None
+        ref = R.scaled_mm_int8(a, b_nk.t(), a_s, b_s, torch.bfloat16, bi)
+        bd = b_nk.to(d).t()
+    out = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=d)
+    ops().cutlass_scaled_mm(out, a.to(d), bd, a_s.to(d), b_s.to(d), bi.to(d) if bias else None)
+    if kind == "fp8":
+        assert_gemm_close(out, ref, f"split-K prefill {m}x{n}x{k}", max_frac=_max_frac(torch.bfloat16))
+    else:
+        assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+
+
 def test_scaled_mm_prepack_not_applicable():
     d = dev()
     b = torch.zeros(1000, 128, dtype=torch.int8, device=d).t()      # n = 1000: not a multiple of 64

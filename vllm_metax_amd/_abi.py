@@ -103,6 +103,7 @@ PROTOTYPES = {
     "mi355x_scaled_mm_fp8": (
         _I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _L, _I, _I, _I, _L, _L, _L, _I, _P]),
     "mi355x_scaled_mm_prepack": (_I, [_P, _P, _I, _I, _L, _P]),
+    "mi355x_scaled_mm_split_elems": (_L, [_I, _I, _I]),
     "mi355x_scaled_mm_prepacked": (
         _I, [_P, _P, _P, _P, _I, _P, _I, _P, _P, _L, _I, _I, _I, _L, _L, _I, _I, _P]),
     "mi355x_scaled_mm_fp8_deferred": (

@@ -1244,7 +1244,9 @@ def scaled_mm_prepacked(out: torch.Tensor, a: torch.Tensor, b_image: torch.Tenso
         raise RuntimeError("scaled_mm_prepacked: float32 contiguous scales, per-tensor or per-row / per-column")
     if bias is not None and (bias.numel() != n or not bias.is_contiguous() or bias.dtype != out.dtype):
         raise RuntimeError("scaled_mm_prepacked: bad bias")
-    ws = None if _scaled_mm_in_place(a, 0, 0)[0] else _scratch_f32(((m + 15) // 16 * 16 * k + 3) // 4, a.device)
+    elems = (0 if _scaled_mm_in_place(a, 0, 0)[0] else (m + 15) // 16 * 16 * k // 4) \
+        + int(_abi.load().mi355x_scaled_mm_split_elems(m, n, k))
+    ws = _scratch_f32(elems, a.device) if elems else None
     rc = _abi.load().mi355x_scaled_mm_prepacked(
         _ptr(out), _ptr(a), _ptr(b_image), _ptr(a_scales), a_scales.numel(), _ptr(b_scales), b_scales.numel(),
         _ptr(bias), _ptr(ws), ws.numel() if ws is not None else 0, m, n, k, a.stride(0), out.stride(0), _dt(out),
@@ -1322,7 +1324,9 @@ def cutlass_scaled_mm(out: torch.Tensor, a: torch.Tensor, b: torch.Tensor,
         # the GEMM reads in place
         a_in_place, b_in_place = _scaled_mm_in_place(a, b.stride(1), b.data_ptr())
         need = (0 if a_in_place else (m + 15) // 16 * 16 * k) + (0 if b_in_place else (n + 15) // 16 * 16 * k)
-        ws = _scratch_f32((need + 3) // 4, a.device) if need else None
+        # + the partial tiles of a K split (shapes with few 256 x 256 tiles)
+        elems = (need + 15) // 16 * 4 + int(_abi.load().mi355x_scaled_mm_split_elems(m, n, k))
+        ws = _scratch_f32(elems, a.device) if elems else None
     else:
         ws = None
     fn = _abi.load().mi355x_scaled_mm_int8 if a.dtype == torch.int8 else _abi.load().mi355x_scaled_mm_fp8

@@ -541,16 +541,20 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
     T* __restrict__ out, const uint4* __restrict__ pa, const uint4* __restrict__ pb,
     const float* __restrict__ a_scales, int a_per_row, const float* __restrict__ b_scales,
     int b_per_col, const T* __restrict__ bias, int m, int n, int k, int64_t ldc, int num_m_blocks,
-    int num_tiles, int64_t lda = 0, int64_t ldb = 0) {
+    int num_tiles, int64_t lda, int64_t ldb, typename Op::elem_t* __restrict__ slabs, int sk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
   constexpr int S = P == 1 ? 4 : 2;       // ring depth
   constexpr int kPiece = 2 * 16 * 64;     // uint4 per 64-k slice: 16 A pieces + 16 B pieces = 32 KiB
   constexpr int kStage = P * kPiece;
   constexpr int kBOff = 16 * 64;
+  // sk > 1 (few tiles: chunked-prefill sized M, narrow N): workgroup (tile, split) runs one K range and leaves its
+  // 4-byte partial tile in slabs[split][m][n]; the finish kernel of the decode path adds the slabs in split order
+  // and applies scales / bias (deterministic, no atomics).  grid = num_tiles * sk, split-major.
+  const int split = blockIdx.x / num_tiles;
   int tile;
   {
-    const int b = blockIdx.x;
+    const int b = blockIdx.x - split * num_tiles;
     const int q = num_tiles / 8, r = num_tiles % 8;
     const int xcd = b % 8;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
@@ -571,7 +575,10 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
   const int wm = wave >> 2, wn = wave & 3;
   const int lc = lane & 15, lr = lane >> 4;
   const int kpieces = k / 64;       // pieces along K
-  const int kstages = kpieces / P;
+  const int kstages_all = kpieces / P;
+  const int per_split = (kstages_all + sk - 1) / sk;
+  const int ks0 = split * per_split;                              // first stage of this workgroup's K range
+  const int kstages = max(0, min(per_split, kstages_all - ks0));
 
   static_assert(P == 2 || !(AROW || BROW), "operands in place: the two-slice stage only");
   // [i][j]: row tile i of this wave; j = k slice of the stage (image) or row half 0-7 / 8-15 (row-major)
@@ -624,8 +631,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
         const int p = wave * 2 + i;
         // a stage advances an image by P pieces of 64 slots, a row by P x 64 bytes = 4 P uint4
         const int dst = buf * kStage + pp * kPiece + p * 64;
-        lds_dma16(a_src[i][pp] + (int64_t)ks * (AROW ? 4 * P : 64 * P), lds_base + dst * 16);
-        lds_dma16(b_src[i][pp] + (int64_t)ks * (BROW ? 4 * P : 64 * P), lds_base + (dst + kBOff) * 16);
+        lds_dma16(a_src[i][pp] + (int64_t)(ks0 + ks) * (AROW ? 4 * P : 64 * P), lds_base + dst * 16);
+        lds_dma16(b_src[i][pp] + (int64_t)(ks0 + ks) * (BROW ? 4 * P : 64 * P), lds_base + (dst + kBOff) * 16);
       }
     }
   };
@@ -730,6 +737,32 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
       }
       cur = cur + 1 == S ? 0 : cur + 1;
     }
+  }
+  if (sk > 1) {
+    // partial tile -> slab of this split (raw accumulators; rows / columns as in the final epilogues below)
+    typename Op::elem_t* sl = slabs + (int64_t)split * m * n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = mb * 256 + wm * 128 + i * 16 + 4 * lr + j;
+        if (row >= m) continue;
+        if constexpr (IL) {
+          const int col = nb * 256 + wn * 64 + 4 * lc;
+          if (col < n) {
+            const typename Op::acc_t v = {acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]};
+            *reinterpret_cast<typename Op::acc_t*>(sl + (int64_t)row * n + col) = v;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int col = nb * 256 + (wn * 4 + t) * 16 + lc;
+            if (col < n) sl[(int64_t)row * n + col] = acc[i][t][j];
+          }
+        }
+      }
+    }
+    return;
   }
   if constexpr (IL) {
     const int col = nb * 256 + wn * 64 + 4 * lc;
@@ -933,6 +966,32 @@ static int run_decode(const Fp8Args& g, int a_per_row, int b_per_col) {
 #undef DEC_NT
 }
 
+// K split of the prefill kernel (gemm8_packed_kernel) for shapes whose 256 x 256 tiles leave most of the chip idle
+// (chunked-prefill sized M, the narrow per-rank N of a TP = 8 shard): sk K ranges per tile, partial tiles through
+// 4-byte slabs [sk][m][n], the decode path's finish kernel.  Cost model in us (fitted to bench_scaled_mm.py:
+// ~1.6 us per 128 k bytes of a tile's loop, ~8 us of prologue + epilogue, slabs written and read back at ~5 TB/s):
+//   t(sk) = rounds(tiles * sk) * (ceil(steps / sk) * 1.6 + 8) + [sk > 1] * (4 + 8 sk m n / 5e6)
+// Every split keeps >= 4 k-steps of 128 bytes and is non-empty; `max_slab_elems` bounds sk by the workspace.
+static int plan_packed_split(int m, int n, int k, int64_t max_slab_elems) {
+  static const int forced = [] { const char* e = getenv("MI355X_F8_PACKED_SK"); return e ? atoi(e) : 0; }();
+  const int tiles = ((m + 255) / 256) * ((n + 255) / 256);
+  const int steps = k / 128;
+  if (tiles >= 160 || steps < 8) return 1;
+  int best = 1;
+  double best_t = 1e30;
+  for (int sk = 1; sk <= 8; ++sk) {
+    const int per = (steps + sk - 1) / sk;
+    if (sk > 1 && (per < 4 || (int64_t)per * (sk - 1) >= steps || (int64_t)sk * m * n > max_slab_elems)) continue;
+    if (forced > 0 && sk != forced && sk != 1) continue;
+    const int rounds = (tiles * sk + 255) / 256;
+    double t = rounds * (per * 1.6 + 8.0);
+    if (sk > 1) t += 4.0 + 8.0 * sk * (double)m * n / 5e6;
+    if (forced > 0 && sk == forced) { best = sk; break; }
+    if (t < best_t) { best_t = t; best = sk; }
+  }
+  return best;
+}
+
 static int f8_rowmajor_bits() {
   static const int bits = [] { const char* e = getenv("MI355X_F8_ROWMAJOR"); return e ? atoi(e) : 3; }();
   return bits;
@@ -964,6 +1023,14 @@ static int run_fp8(const Fp8Args& g) {
     if (g.m >= kPackedMinM && (need == 0 || (g.ws != nullptr && g.ws_elems * 4 >= need &&
                                              (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0)) &&
         g.k % 64 == 0) {
+      // what the workspace holds beyond the operand images: slabs of a K split
+      typename Op::elem_t* slabs = nullptr;
+      int sk = 1;
+      if (g.ws != nullptr && (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0) {
+        const int64_t img_elems = (need + 15) / 16 * 4;
+        sk = plan_packed_split(g.m, g.n, g.k, g.ws_elems - img_elems);
+        slabs = reinterpret_cast<typename Op::elem_t*>(g.ws) + img_elems;
+      }
       bf16_t* ws16 = reinterpret_cast<bf16_t*>(g.ws);
       const void* pa = arow ? g.a : static_cast<const void*>(ws16);
       bf16_t* pb_ws = arow ? ws16 : ws16 + m_pad * g.k / 2;
@@ -997,10 +1064,10 @@ static int run_fp8(const Fp8Args& g) {
           }
           once.mark(dev);
         }
-        hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(512), smem, g.stream, out,
+        hipLaunchKernelGGL(kern, dim3(num_tiles * sk), dim3(512), smem, g.stream, out,
                            reinterpret_cast<const uint4*>(pa), reinterpret_cast<const uint4*>(pb),
                            g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.k, g.ldc,
-                           num_m_blocks, num_tiles, g.lda, g.ldb);
+                           num_m_blocks, num_tiles, g.lda, g.ldb, slabs, sk);
         return 0;
       };
       static PerDeviceOnce attr[8];   // per kernel variant, one bit per device
@@ -1019,7 +1086,16 @@ static int run_fp8(const Fp8Args& g) {
                 : launch(gemm8_packed_kernel<T, Op, 1, false>, attr[0]);
       }
       if (rc) return rc;
-      return check_launch("scaled_mm(packed)");
+      rc = check_launch("scaled_mm(packed)");
+      if (rc || sk == 1) return rc;
+      if (g.n % 4 == 0 && g.ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0) {
+        hipLaunchKernelGGL((fp8_gemm_finish4_kernel<T, Op>), dim3((g.m * (g.n / 4) + 255) / 256), dim3(256), 0,
+                           g.stream, out, slabs, g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.ldc, sk);
+      } else {
+        hipLaunchKernelGGL((fp8_gemm_finish_kernel<T, Op>), dim3((g.n + 255) / 256, g.m), dim3(256), 0, g.stream, out,
+                           slabs, g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.ldc, sk);
+      }
+      return check_launch("scaled_mm(packed finish)");
     }
   }
   // 64 < M <= 320 (decode batches above 64 sequences, small chunked-prefill budgets): passes of 64 rows through the
@@ -1119,6 +1195,14 @@ extern "C" int mi355x_scaled_mm_fp8(void* out, const void* a, const void* b,
             a_scales_numel, b_scales, b_scales_numel, bias, m, n, k, lda, ldb, ldc, workspace,
             workspace_elems, static_cast<hipStream_t>(stream)};
   return MI355X_DISPATCH_HALF(out_dtype, [&] { return run_fp8<scalar_t, OpFp8>(g); });
+}
+
+// 4-byte workspace elements the prefill kernel (m > 320) wants ON TOP of the operand-image scratch to split K for a
+// shape with few 256 x 256 tiles (0: no split) — what a binding adds to the workspace it passes to mi355x_scaled_mm_*.
+extern "C" int64_t mi355x_scaled_mm_split_elems(int m, int n, int k) {
+  if (m <= 320 || n <= 0 || k <= 0 || k % 64 != 0) return 0;
+  const int sk = plan_packed_split(m, n, k, INT64_MAX);
+  return sk > 1 ? (int64_t)sk * m * n : 0;
 }
 
 // Load-time weight image of the 8-bit GEMM's packed path (fp8 and int8 alike: bytes): what pack_a_kernel derives

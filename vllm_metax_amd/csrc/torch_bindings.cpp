@@ -441,7 +441,9 @@ void cutlass_scaled_mm(Tensor& out, const Tensor& a, const Tensor& b, const Tens
     const bool b_in_place = a_in_place && (bits & 2) && b.stride(1) % 16 == 0 &&
                             reinterpret_cast<uintptr_t>(b.data_ptr()) % 16 == 0;
     const int64_t need = (a_in_place ? 0 : (m + 15) / 16 * 16 * k) + (b_in_place ? 0 : (n + 15) / 16 * 16 * k);
-    if (need) ws = at::empty({(need + 3) / 4}, a.options().dtype(at::kFloat));
+    // + the partial tiles of a K split (shapes with few 256 x 256 tiles)
+    const int64_t elems = (need + 15) / 16 * 4 + mi355x_scaled_mm_split_elems((int)m, (int)n, (int)k);
+    if (elems) ws = at::empty({elems}, a.options().dtype(at::kFloat));
   }
   auto fn = is_i8 ? mi355x_scaled_mm_int8 : mi355x_scaled_mm_fp8;   // scaled_mm_entry.cu:34-39 / new
   ok(fn(out.data_ptr(), a.data_ptr(), b.data_ptr(), a_scales.data_ptr<float>(), a_scales.numel(),
