@@ -183,3 +183,35 @@ def test_decode_partition_size_and_workspace():
                           num_heads=8, head_size=128, dtype=torch.bfloat16, workspace=ws, num_kv_heads=1,
                           fixed_decode_len=1152)
     assert md.partition_size == 288 and md.exp_sums.shape == (64, 8, 4) and md.use_v1 is False
+
+
+def test_scaled_mm_operands_in_place_rule(monkeypatch):
+    """Which operands of the m > 320 8-bit GEMM need no operand image (and therefore no scratch): fp8, k % 128 == 0,
+    16-byte aligned rows — the rule of fp8_gemm.hip run_fp8, mirrored by the bindings for the workspace they pass."""
+    from vllm_metax_amd import _custom_ops as ops
+    monkeypatch.delenv("MI355X_F8_ROWMAJOR", raising=False)
+    a = torch.zeros(512, 4096, dtype=torch.uint8).view(torch.float8_e4m3fn)
+    assert ops._scaled_mm_in_place(a, 4096, 0) == (True, True)
+    assert ops._scaled_mm_in_place(a, 4100, 0) == (True, False)            # weight rows not 16-byte aligned
+    assert ops._scaled_mm_in_place(a[:, :4032], 4096, 0) == (False, False)  # k % 128 != 0: the 64-byte-stage kernel
+    assert ops._scaled_mm_in_place(torch.zeros(512, 4096, dtype=torch.int8), 4096, 0) == (False, False)
+    wide = torch.zeros(512, 4096 + 8, dtype=torch.uint8).view(torch.float8_e4m3fn)
+    assert ops._scaled_mm_in_place(wide[:, :4096], 4096, 0) == (False, False)   # activation rows 8 bytes off
+    monkeypatch.setenv("MI355X_F8_ROWMAJOR", "1")
+    assert ops._scaled_mm_in_place(a, 4096, 0) == (True, False)
+    monkeypatch.setenv("MI355X_F8_ROWMAJOR", "0")
+    assert ops._scaled_mm_in_place(a, 4096, 0) == (False, False)
+
+
+def test_scaled_mm_split_plan_is_a_host_function():
+    """mi355x_scaled_mm_split_elems (host-only planner, no GPU call): sk * m * n workspace elements for shapes whose
+    256 x 256 tiles leave the chip mostly idle, 0 where the prefill kernel is not split."""
+    from vllm_metax_amd import _abi
+    f = _abi.load().mi355x_scaled_mm_split_elems
+    assert f(576, 4096, 4096) == 4 * 576 * 4096          # 48 tiles, 32 k-steps
+    assert f(2048, 1280, 8192) == 5 * 2048 * 1280        # one TP = 8 rank's qkv at a 2048-token chunk
+    assert f(8192, 28672, 4096) == 0 and f(8192, 1280, 8192) == 0     # >= 160 tiles
+    assert f(2048, 8192, 1024) == 0                      # 256 tiles
+    assert f(512, 512, 512) == 0                         # 4 k-steps: nothing to split
+    assert f(64, 4096, 4096) == 0 and f(320, 4096, 4096) == 0        # decode-kernel territory
+    assert f(576, 4096, 4000) == 0                       # k % 64 != 0: not the prefill kernel's shape

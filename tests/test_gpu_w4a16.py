@@ -339,6 +339,31 @@ def test_prepacked_weight_image_is_bit_identical(dtype, quant):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k,n", [(576, 4096, 1024), (400, 2048, 320), (1100, 4096, 512), (2048, 8192, 1280)])
+def test_prepacked_image_gemm_mid_m_and_split_k(dtype, m, k, n):
+    """mi355x_w4a16_gemm_prepacked below 1024 rows (from 384: chunked-prefill budgets) and on shapes with few
+    256 x 256 tiles, where it splits K through fp32 slabs (mi355x_w4a16_prepacked_split_elems > 0): the oracle within
+    the GEMM tolerance; at m >= 1024 the per-call awq_gemm plans the same split and stays bit-identical."""
+    from vllm_metax_amd import _abi
+    assert _abi.load().mi355x_w4a16_prepacked_split_elems(m, n, k) >= 2 * m * n
+    qw, qz, sc, _, _ = make_awq(k, n, 128, dtype, seed=m)
+    x = (torch.randn(m, k, generator=torch.Generator().manual_seed(k)) * 0.5).to(dtype)
+    ref = R.awq_gemm(x, R.awq_to_gptq_4bit(qw), sc, qz)
+    d = dev()
+    q2d, qzd, scd = ops().awq_to_gptq_4bit(qw.to(d)), qz.to(d), sc.to(d)
+    img = ops().w4a16_prepack(q2d, qzd, scd, False)
+    out = ops().w4a16_gemm_prepacked(x.to(d), img, n, k)
+    _check_gemm(out, ref, f"image gemm {m}x{k}x{n}")
+    per_call = ops().awq_gemm(x.to(d), q2d, qzd, scd, 8, torch.empty(0), dtype == torch.bfloat16)
+    if m >= 1024:
+        assert_bit_exact(out, per_call, "image gemm == per-call gemm at the same m")
+    else:
+        _check_gemm(per_call, ref, f"stripe passes {m}x{k}x{n}")
+    with pytest.raises(RuntimeError):
+        ops().w4a16_gemm_prepacked(x[:320].to(d), img, n, k)      # below W4_PREPACKED_MIN_M
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("m,k,n", [(1, 256, 128), (33, 1024, 320), (64, 4096, 512), (100, 512, 64), (1100, 512, 256)])
 @pytest.mark.parametrize("sym", [True, False])
 def test_gptq_gemm_8bit(dtype, m, k, n, sym):

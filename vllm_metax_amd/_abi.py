@@ -81,6 +81,7 @@ PROTOTYPES = {
     "mi355x_awq_gemm_packed_a": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "mi355x_w4a16_prepack": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mi355x_w4a16_gemm_prepacked": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _L, _I, _I, _P]),
+    "mi355x_w4a16_prepacked_split_elems": (_L, [_I, _I, _I]),
     "mi355x_gptq_shuffle": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "mi355x_gptq_gemm": (
         _I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _P]),

@@ -634,7 +634,8 @@ def _dq_scratch(m: int, n: int, k: int, device) -> Optional[torch.Tensor]:
     elif m < 1024:
         need = 8 * 128 * n * 4                  # 64 < m < 1024: fp32 split-K slabs of one 128-row pass
     else:
-        need = (n + m_pad) * k * 2              # prefill: packed weights + packed activations
+        # prefill: packed weights + packed activations + the partial tiles of a K split (few 256 x 256 tiles)
+        need = ((n + m_pad) * k * 2 + 15) // 16 * 16 + 4 * int(_abi.load().mi355x_w4a16_prepacked_split_elems(m, n, k))
     return _grow(_DQ_SCRATCH, device, need, torch.uint8)
 
 
@@ -1048,9 +1049,12 @@ def w4a16_prepack(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Ten
     return image
 
 
+W4_PREPACKED_MIN_M = 384     # smallest m mi355x_w4a16_gemm_prepacked takes (csrc/w4a16.cuh kW4PrepackedMinM)
+
+
 def w4a16_gemm_prepacked(a, image: torch.Tensor, n: int, k: int, silu: bool = False,
                          out_image: bool = False):
-    """a [m, k] (row-major tensor or PackedOperand) times a prepacked weight image (m >= 1024).
+    """a [m, k] (row-major tensor or PackedOperand) times a prepacked weight image (m >= W4_PREPACKED_MIN_M).
     silu: gate_up projection, returns silu_and_mul(a . W) [m, n/2]; out_image (with silu): returns it
     as a PackedOperand for the next GEMM.  Bit-identical to awq_gemm (+ silu_and_mul) at the same m."""
     packed_in = isinstance(a, PackedOperand)
@@ -1063,10 +1067,14 @@ def w4a16_gemm_prepacked(a, image: torch.Tensor, n: int, k: int, silu: bool = Fa
         (PREPACKED_A_IMAGE if packed_in else 0)
     m_pad = (m + 15) // 16 * 16
     ws = None
+    # partial tiles of a K split behind the activation image (plain epilogue, shapes with few 256 x 256 tiles)
+    split_bytes = 0 if silu else 4 * int(_abi.load().mi355x_w4a16_prepacked_split_elems(m, n, k))
     if not packed_in:
         if a.dim() != 2 or a.stride(1) != 1:
             raise RuntimeError("w4a16_gemm_prepacked: input must be [M, K] with unit inner stride")
-        ws = _a_scratch(m_pad * k * 2, data.device)
+        ws = _a_scratch(m_pad * k * 2 + split_bytes, data.device)
+    elif split_bytes:
+        ws = _a_scratch(split_bytes, data.device)
     if out_image:
         out = torch.empty(m_pad * (n // 2), dtype=data.dtype, device=data.device)
     else:

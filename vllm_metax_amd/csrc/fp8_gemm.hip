@@ -966,30 +966,10 @@ static int run_decode(const Fp8Args& g, int a_per_row, int b_per_col) {
 #undef DEC_NT
 }
 
-// K split of the prefill kernel (gemm8_packed_kernel) for shapes whose 256 x 256 tiles leave most of the chip idle
-// (chunked-prefill sized M, the narrow per-rank N of a TP = 8 shard): sk K ranges per tile, partial tiles through
-// 4-byte slabs [sk][m][n], the decode path's finish kernel.  Cost model in us (fitted to bench_scaled_mm.py:
-// ~1.6 us per 128 k bytes of a tile's loop, ~8 us of prologue + epilogue, slabs written and read back at ~5 TB/s):
-//   t(sk) = rounds(tiles * sk) * (ceil(steps / sk) * 1.6 + 8) + [sk > 1] * (4 + 8 sk m n / 5e6)
-// Every split keeps >= 4 k-steps of 128 bytes and is non-empty; `max_slab_elems` bounds sk by the workspace.
+// K split of the prefill kernel (gemm8_packed_kernel): plan_tile_split (w4a16.cuh); MI355X_F8_PACKED_SK for A/B runs
 static int plan_packed_split(int m, int n, int k, int64_t max_slab_elems) {
   static const int forced = [] { const char* e = getenv("MI355X_F8_PACKED_SK"); return e ? atoi(e) : 0; }();
-  const int tiles = ((m + 255) / 256) * ((n + 255) / 256);
-  const int steps = k / 128;
-  if (tiles >= 160 || steps < 8) return 1;
-  int best = 1;
-  double best_t = 1e30;
-  for (int sk = 1; sk <= 8; ++sk) {
-    const int per = (steps + sk - 1) / sk;
-    if (sk > 1 && (per < 4 || (int64_t)per * (sk - 1) >= steps || (int64_t)sk * m * n > max_slab_elems)) continue;
-    if (forced > 0 && sk != forced && sk != 1) continue;
-    const int rounds = (tiles * sk + 255) / 256;
-    double t = rounds * (per * 1.6 + 8.0);
-    if (sk > 1) t += 4.0 + 8.0 * sk * (double)m * n / 5e6;
-    if (forced > 0 && sk == forced) { best = sk; break; }
-    if (t < best_t) { best_t = t; best = sk; }
-  }
-  return best;
+  return plan_tile_split(m, n, k / 128, max_slab_elems, forced);
 }
 
 static int f8_rowmajor_bits() {

@@ -340,7 +340,9 @@ Tensor awq_gemm(Tensor in_feats, Tensor kernel, Tensor scaling_factors, Tensor z
     ws_elems = temp_space.numel();
   }
   Tensor dq;  // scratch for the dequantised weights of prefill-sized GEMMs
-  if (m >= 1024) dq = at::empty({(n + (m + 15) / 16 * 16) * k * 2}, in_feats.options().dtype(at::kByte));
+  if (m >= 1024)   // operand images + the partial tiles of a K split (shapes with few 256 x 256 tiles)
+    dq = at::empty({(n + (m + 15) / 16 * 16) * k * 2 + 4 * mi355x_w4a16_prepacked_split_elems((int)m, (int)n, (int)k)},
+                   in_feats.options().dtype(at::kByte));
   else if (m > 64) dq = at::empty({8 * 128 * n * 4}, in_feats.options().dtype(at::kByte));   // split-K slabs of a 128-row pass
   ok(mi355x_awq_gemm(out.data_ptr(), in_feats.data_ptr(),
                      static_cast<const uint32_t*>(kernel.data_ptr()), scaling_factors.data_ptr(),
@@ -393,7 +395,9 @@ Tensor gptq_gemm(Tensor a, Tensor b_q_weight, Tensor b_gptq_qzeros, Tensor b_gpt
     ws_elems = temp_space.numel();
   }
   Tensor dq;
-  if (m >= 1024) dq = at::empty({(n + (m + 15) / 16 * 16) * k * 2}, a.options().dtype(at::kByte));
+  if (m >= 1024)   // operand images + the partial tiles of a K split (shapes with few 256 x 256 tiles)
+    dq = at::empty({(n + (m + 15) / 16 * 16) * k * 2 + 4 * mi355x_w4a16_prepacked_split_elems((int)m, (int)n, (int)k)},
+                   a.options().dtype(at::kByte));
   else if (m > 64) dq = at::empty({8 * 128 * n * 4}, a.options().dtype(at::kByte));   // split-K slabs of a 128-row pass
   ok(mi355x_gptq_gemm(out.data_ptr(), a.data_ptr(),
                       static_cast<const uint32_t*>(b_q_weight.data_ptr()),

@@ -184,6 +184,33 @@ __global__ __launch_bounds__(256) void pack_a_kernel(T* __restrict__ packed, con
   for (int idx = threadIdx.x; idx < pieces * 64; idx += 256) dst[idx] = img[idx];
 }
 
+// K split of the 256 x 256-tile prefill kernels (gemm_packed_kernel, gemm8_packed_kernel) for shapes whose tiles leave
+// most of the chip idle (chunked-prefill sized M, the narrow per-rank N of a TP = 8 shard): sk K ranges per tile,
+// partial tiles through 4-byte slabs [sk][m][n] and a finish kernel that adds them in split order.  steps = the
+// tile loop's length in 128-byte k-steps (fp8 / int8: k / 128; 2-byte operands: k / 64).  Cost model in us (fitted
+// to scripts/bench_scaled_mm.py: ~1.6 us per k-step, ~8 us of prologue + epilogue, slabs written and read back at
+// ~5 TB/s):  t(sk) = rounds(tiles * sk) * (ceil(steps / sk) * 1.6 + 8) + [sk > 1] * (4 + 8 sk m n / 5e6).
+// Every split keeps >= 4 k-steps and is non-empty; `max_slab_elems` bounds sk by the workspace; forced > 0: that sk
+// (or 1 where it is not admissible).
+constexpr int kW4PrepackedMinM = 384;   // smallest m the operand-image GEMM takes when the weights' image exists
+static inline int plan_tile_split(int m, int n, int steps, int64_t max_slab_elems, int forced) {
+  const int tiles = ((m + 255) / 256) * ((n + 255) / 256);
+  if (tiles >= 160 || steps < 8) return 1;
+  int best = 1;
+  double best_t = 1e30;
+  for (int sk = 1; sk <= 8; ++sk) {
+    const int per = (steps + sk - 1) / sk;
+    if (sk > 1 && (per < 4 || (int64_t)per * (sk - 1) >= steps || (int64_t)sk * m * n > max_slab_elems)) continue;
+    if (forced > 0 && sk != forced && sk != 1) continue;
+    const int rounds = (tiles * sk + 255) / 256;
+    double t = rounds * (per * 1.6 + 8.0);
+    if (sk > 1) t += 4.0 + 8.0 * sk * (double)m * n / 5e6;
+    if (forced > 0 && sk == forced) { best = sk; break; }
+    if (t < best_t) { best_t = t; best = sk; }
+  }
+  return best;
+}
+
 // out = T(slab[0] + slab[1] + ... + slab[sk-1])  (fixed order: results do not depend on timing)
 template <typename T>
 __global__ void w4a16_sum_slabs_kernel(T* __restrict__ out, const float* __restrict__ slabs,

@@ -793,10 +793,18 @@ int mi355x_w4a16_gemm_prepacked(void* out, const void* a, const void* image, voi
   }
   const int rc = w4a16_gemm_unfused_dispatch(g, dtype);
   MI355X_REQUIRE(rc != 1, MI355X_EUNSUPPORTED,
-                 "w4a16_gemm_prepacked: needs a 2-byte dtype, m >= 1024 (n %% 256 == 0 with SILU) and an "
+                 "w4a16_gemm_prepacked: needs a 2-byte dtype, m >= 384 (n %% 256 == 0 with SILU) and an "
                  "activation workspace of roundup(m,16)*k*2 bytes (got m=%d n=%d k=%d, %lld bytes)",
                  m, n, k, (long long)a_workspace_bytes);
   return rc;
+}
+
+// 4-byte workspace elements mi355x_w4a16_gemm_prepacked (plain epilogue) wants ON TOP of the activation image to
+// split K for a shape with few 256 x 256 tiles (0: no split)
+int64_t mi355x_w4a16_prepacked_split_elems(int m, int n, int k) {
+  if (m < kW4PrepackedMinM || n <= 0 || k <= 0 || n % 64 != 0 || k % 32 != 0) return 0;
+  const int sk = plan_tile_split(m, n, k / 64, INT64_MAX, 0);
+  return sk > 1 ? (int64_t)sk * m * n : 0;
 }
 
 int mi355x_gptq_gemm(void* c, const void* a, const uint32_t* qweight,

@@ -129,16 +129,20 @@ constexpr int kUfThreads = 512;
 template <typename T, int MODE>
 __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
     T* __restrict__ c, const uint4* __restrict__ pa, const uint4* __restrict__ pb, int m, int n,
-    int k, int num_m_blocks, int num_tiles) {
+    int k, int num_m_blocks, int num_tiles, float* __restrict__ slabs, int sk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* lds = reinterpret_cast<uint4*>(smem);
   // per stage: A pieces [16 mt][64] then B pieces [16 nt][64]  (uint4 units)
   constexpr int kStage = 2 * 16 * 64;  // 2048 uint4 = 32 KiB
   constexpr int kBOff = 16 * 64;
 
+  // sk > 1 (MODE 0 only; few tiles: chunked-prefill sized M, narrow N): workgroup (tile, split) runs one K range
+  // and leaves its fp32 partial tile in slabs[split][m][n]; w4a16_sum_slabs_kernel adds them in split order and
+  // rounds to T (deterministic, no atomics).  grid = num_tiles * sk, split-major.
+  const int split = blockIdx.x / num_tiles;
   int tile;
   {
-    const int b = blockIdx.x;
+    const int b = blockIdx.x - split * num_tiles;
     const int q = num_tiles / 8, r = num_tiles % 8;
     const int xcd = b % 8;
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
@@ -165,8 +169,10 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   const int wn = wave & 3;    // 0..3 : 64-column group
   const int lc = lane & 15;
   const int lr = lane >> 4;
-  const int ktiles = k / kUfBK;
   const int kt32 = k >> 5;
+  const int per_split = (kt32 + sk - 1) / sk;
+  const int kt0 = split * per_split;                              // first stage of this workgroup's K range
+  const int ktiles = max(0, min(per_split, kt32 - kt0));
 
   // staging: wave w copies A pieces 2w, 2w+1 and B pieces 2w, 2w+1 of each stage
   // (piece = 16-row tile; its successive k-steps are adjacent in global memory)
@@ -190,8 +196,8 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int p = wave * 2 + i;
-      lds_dma16(a_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + p * 64) * 16);
-      lds_dma16(b_src[i] + (int64_t)kt * 64, lds_base + (buf * kStage + kBOff + p * 64) * 16);
+      lds_dma16(a_src[i] + (int64_t)(kt0 + kt) * 64, lds_base + (buf * kStage + p * 64) * 16);
+      lds_dma16(b_src[i] + (int64_t)(kt0 + kt) * 64, lds_base + (buf * kStage + kBOff + p * 64) * 16);
     }
   };
   constexpr int kPerStage = 4;  // copies one wave issues per stage
@@ -314,6 +320,20 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   }
   const int ncol = nb * kUfBN + wn * 64 + 4 * lc;
   if (ncol >= n) return;
+  if (sk > 1) {
+    float* sl = slabs + (int64_t)split * m * n;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = mb * kUfBM + wm * 128 + i * 16 + 4 * lr + j;
+        if (row < m)
+          *reinterpret_cast<f32x4_t*>(sl + (int64_t)row * n + ncol) =
+              f32x4_t{acc[i][0][j], acc[i][1][j], acc[i][2][j], acc[i][3][j]};
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -411,10 +431,28 @@ static int run_unfused(const GemmArgs& g) {
     }
     attr_once.mark(dev);
   }
-  hipLaunchKernelGGL(kern, dim3(num_tiles), dim3(kUfThreads), smem, g.stream, static_cast<T*>(g.c),
+  // K split (plain epilogue only) where the tiles leave most of the chip idle: slabs behind the operand images
+  int sk = 1;
+  float* slabs = nullptr;
+  if constexpr (MODE == 0) {
+    static const int forced = [] { const char* e = getenv("MI355X_W4_PACKED_SK"); return e ? atoi(e) : 0; }();
+    const int64_t img_bytes = ((g.b_image ? 0 : (int64_t)g.n * g.k * 2) +
+                               (g.a_packed ? 0 : (((int64_t)g.m + 15) / 16 * 16) * g.k * 2) + 15) / 16 * 16;
+    if (g.dq_ws != nullptr && g.dq_ws_bytes > img_bytes && (reinterpret_cast<uintptr_t>(g.dq_ws) & 15) == 0 &&
+        g.n % 4 == 0 && (reinterpret_cast<uintptr_t>(g.c) & 7) == 0) {
+      sk = plan_tile_split(g.m, g.n, g.k / 64, (g.dq_ws_bytes - img_bytes) / 4, forced);
+      slabs = reinterpret_cast<float*>(static_cast<char*>(g.dq_ws) + img_bytes);
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(num_tiles * sk), dim3(kUfThreads), smem, g.stream, static_cast<T*>(g.c),
                      reinterpret_cast<const uint4*>(packed_a), reinterpret_cast<const uint4*>(packed_b),
-                     g.m, g.n, g.k, num_m_blocks, num_tiles);
-  return check_launch("gemm_packed");
+                     g.m, g.n, g.k, num_m_blocks, num_tiles, slabs, sk);
+  rc = check_launch("gemm_packed");
+  if (rc || sk == 1) return rc;
+  const int64_t n4 = (int64_t)g.m * g.n / 4;
+  hipLaunchKernelGGL(w4a16_sum_slabs_kernel<T>, dim3((n4 + 255) / 256), dim3(256), 0, g.stream, static_cast<T*>(g.c),
+                     slabs, n4, sk);
+  return check_launch("gemm_packed(sum)");
 }
 
 // returns 1 when not applicable (caller uses the fused kernel)
@@ -428,7 +466,10 @@ int w4a16_gemm_unfused_dispatch(const GemmArgs& g, int dtype) {
     if (g.dq_ws_bytes < unfused_scratch_bytes(g.m, g.n, g.k)) return 1;
   }
   if (g.k % kUfBK != 0 || g.n % 64 != 0) return 1;
-  if (g.m < 1024) return 1;   // too few 256-row tiles to fill 256 CUs below that
+  // too few 256-row tiles to fill 256 CUs below 1024 rows — unless the weights' image exists already (no per-call
+  // dequantisation of the whole matrix) and the plain epilogue can split K (run_unfused): then from 384 rows
+  // (Llama-3-8B layer at M = 576: stripe passes 5 x ~100 us against ... see profiles/r03_w4a16_mid_m_image.txt)
+  if (g.m < (g.b_image != nullptr ? kW4PrepackedMinM : 1024)) return 1;
   if (g.fuse_silu) {
     if (g.n % 256 != 0) return 1;   // gate and up halves must each be whole 128-column blocks
     if (g.out_packed) {

@@ -172,7 +172,9 @@ class QLinear:
 
     def __call__(self, x) -> torch.Tensor:
         m = x.shape[0]
-        if m >= 1024 and self.image() is not None:
+        # (with the weights' image at hand the image GEMM — K split for the narrow projections — beats the 128-row
+        #  stripe passes from 384 rows on; without it 1024, where deriving the image per call pays)
+        if m >= ops.W4_PREPACKED_MIN_M and self.image() is not None:
             return ops.w4a16_gemm_prepacked(x, self.image(), self.n, self.k)
         if isinstance(x, ops.PackedOperand):     # prefill: activations already re-tiled by the producer
             return ops.awq_gemm_packed_a(x, self.qweight, self.qzeros, self.scales)
@@ -218,7 +220,7 @@ class QLinear:
 
     def silu_mul(self, x: torch.Tensor):
         """silu_and_mul(self(x)) in one launch where the library supports it (AWQ, M >= 1024), else None."""
-        if x.shape[0] >= 1024 and self.n % 256 == 0 and self.image() is not None:
+        if x.shape[0] >= ops.W4_PREPACKED_MIN_M and self.n % 256 == 0 and self.image() is not None:
             return ops.w4a16_gemm_prepacked(x, self.image(), self.n, self.k, silu=True,
                                             out_image=self.packed_silu)
         if self.quant == "awq":

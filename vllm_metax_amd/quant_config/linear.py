@@ -18,7 +18,7 @@ from .. import envs
 # keep it as `layer._mi355x_prefill_image` and hand it to apply_awq / apply_gptq (`image=`) or to
 # apply_w4a16_image — never a table keyed by a device address (a freed-and-reused address would serve
 # another layer's weights).
-PREFILL_IMAGE_MIN_M = 1024
+PREFILL_IMAGE_MIN_M = 384     # = _custom_ops.W4_PREPACKED_MIN_M (was 1024 before the image GEMM could split K)
 IMAGE_ATTR = "_mi355x_prefill_image"
 
 
