@@ -402,9 +402,12 @@ int mi355x_w4a16_prepack(void* image, const uint32_t* qweight, const void* scale
  * a_workspace: roundup(m,16) * k * sizeof(T) bytes for the activation image (unused with A_IMAGE).
  * m >= 384 (the per-call forms mi355x_awq_gemm / _gptq_gemm switch to the image GEMM at m >= 1024, where deriving
  * the image per call pays; with the image at hand 384 rows do).  Shapes with few 256 x 256 output tiles (chunked-
- * prefill sized m, a TP shard's narrow n) split K in the plain (mode without SILU) form when a_workspace has
- * room behind the activation image: mi355x_w4a16_prepacked_split_elems returns the 4-byte elements to add for
- * that (0: not split); fp32 partial tiles, added in split order by one more launch. */
+ * prefill sized m, a TP shard's narrow n) split K when a_workspace has room behind the activation image:
+ * mi355x_w4a16_prepacked_split_elems returns the 4-byte elements to add for that (0: not split); fp32 partial
+ * tiles, added in split order by one more launch (which also applies the SILU epilogue / writes the OUT_IMAGE).
+ * The per-call forms (mi355x_awq_gemm / _gptq_gemm / .._silu_mul / .._silu_mul_packed / .._packed_a at m >= 1024)
+ * plan the same split from dq_workspace bytes beyond their operand images, so that all forms agree bit for bit
+ * when each is given those elements. */
 enum { MI355X_PREPACKED_SILU = 1, MI355X_PREPACKED_OUT_IMAGE = 2, MI355X_PREPACKED_A_IMAGE = 4 };
 int64_t mi355x_w4a16_prepacked_split_elems(int m, int n, int k);
 int mi355x_w4a16_gemm_prepacked(void* out, const void* a, const void* image, void* a_workspace,

@@ -359,6 +359,16 @@ def test_prepacked_image_gemm_mid_m_and_split_k(dtype, m, k, n):
         assert_bit_exact(out, per_call, "image gemm == per-call gemm at the same m")
     else:
         _check_gemm(per_call, ref, f"stripe passes {m}x{k}x{n}")
+    if n % 256 == 0:
+        # the split forms of the SILU epilogue (row-major and operand image): the bits of the plain split GEMM
+        # followed by silu_and_mul
+        act = torch.empty(m, n // 2, dtype=dtype, device=d)
+        ops().silu_and_mul(act, out)
+        assert_bit_exact(ops().w4a16_gemm_prepacked(x.to(d), img, n, k, silu=True), act, "split K + silu epilogue")
+        packed = ops().w4a16_gemm_prepacked(x.to(d), img, n, k, silu=True, out_image=True)
+        unp = _unpack_operand(packed, m, n // 2)
+        assert_bit_exact(unp[:m], act, "split K + silu epilogue -> operand image")
+        assert not unp[m:].view(torch.int16).any(), "rows >= m of the image must be zero"
     with pytest.raises(RuntimeError):
         ops().w4a16_gemm_prepacked(x[:320].to(d), img, n, k)      # below W4_PREPACKED_MIN_M
 

@@ -1067,8 +1067,8 @@ def w4a16_gemm_prepacked(a, image: torch.Tensor, n: int, k: int, silu: bool = Fa
         (PREPACKED_A_IMAGE if packed_in else 0)
     m_pad = (m + 15) // 16 * 16
     ws = None
-    # partial tiles of a K split behind the activation image (plain epilogue, shapes with few 256 x 256 tiles)
-    split_bytes = 0 if silu else 4 * int(_abi.load().mi355x_w4a16_prepacked_split_elems(m, n, k))
+    # partial tiles of a K split behind the activation image (shapes with few 256 x 256 tiles)
+    split_bytes = 4 * int(_abi.load().mi355x_w4a16_prepacked_split_elems(m, n, k))
     if not packed_in:
         if a.dim() != 2 or a.stride(1) != 1:
             raise RuntimeError("w4a16_gemm_prepacked: input must be [M, K] with unit inner stride")

@@ -799,10 +799,10 @@ int mi355x_w4a16_gemm_prepacked(void* out, const void* a, const void* image, voi
   return rc;
 }
 
-// 4-byte workspace elements mi355x_w4a16_gemm_prepacked (plain epilogue) wants ON TOP of the activation image to
-// split K for a shape with few 256 x 256 tiles (0: no split)
+// 4-byte workspace elements the operand-image GEMM wants ON TOP of its operand images to split K for a shape with
+// few 256 x 256 tiles (0: no split)
 int64_t mi355x_w4a16_prepacked_split_elems(int m, int n, int k) {
-  if (m < kW4PrepackedMinM || n <= 0 || k <= 0 || n % 64 != 0 || k % 32 != 0) return 0;
+  if (m < kW4PrepackedMinM || n <= 0 || k <= 0 || n % 64 != 0 || k % 32 != 0 || n % 16 != 0) return 0;
   const int sk = plan_tile_split(m, n, k / 64, INT64_MAX, 0);
   return sk > 1 ? (int64_t)sk * m * n : 0;
 }

@@ -136,9 +136,11 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   constexpr int kStage = 2 * 16 * 64;  // 2048 uint4 = 32 KiB
   constexpr int kBOff = 16 * 64;
 
-  // sk > 1 (MODE 0 only; few tiles: chunked-prefill sized M, narrow N): workgroup (tile, split) runs one K range
-  // and leaves its fp32 partial tile in slabs[split][m][n]; w4a16_sum_slabs_kernel adds them in split order and
-  // rounds to T (deterministic, no atomics).  grid = num_tiles * sk, split-major.
+  // sk > 1 (few tiles: chunked-prefill sized M, narrow N): workgroup (tile, split) runs one K range and leaves its
+  // fp32 partial tile in slabs[split][m][n] (SILU: gate and up columns at their places in [m][n]); a finish kernel
+  // adds the slabs in split order, rounds to T and — SILU — applies silu_and_mul on the T values, writing act
+  // row-major or as the operand image: the bits of the plain split GEMM followed by the two ops (deterministic, no
+  // atomics).  grid = num_tiles * sk, split-major.
   const int split = blockIdx.x / num_tiles;
   int tile;
   {
@@ -263,6 +265,27 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
   if (wave < 4) __builtin_amdgcn_s_barrier();
 
   // ---- epilogue: lane holds 4 consecutive columns per (i, j) --------------------------------
+  if constexpr (SILU) {
+    if (sk > 1) {
+      // tiles t = 0,1: gate columns col, col+1; t = 2,3: the same columns of the up half
+      const int half = n >> 1;
+      const int col = nb * 128 + 64 * (wn >> 1) + 4 * lc + 2 * (wn & 1);
+      if (col >= half) return;
+      float* sl = slabs + (int64_t)split * m * n;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = mb * kUfBM + wm * 128 + i * 16 + 4 * lr + j;
+          if (row < m) {
+            *reinterpret_cast<float2*>(sl + (int64_t)row * n + col) = make_float2(acc[i][0][j], acc[i][1][j]);
+            *reinterpret_cast<float2*>(sl + (int64_t)row * n + half + col) = make_float2(acc[i][2][j], acc[i][3][j]);
+          }
+        }
+      }
+      return;
+    }
+  }
   if constexpr (MODE == 2) {
     // (n % 256 == 0: every tile is 128 whole act columns; rows >= m of the last row tile are zero
     // in the packed A, so their results are silu(0) * 0 = 0, as pack_a_kernel would write them)
@@ -345,6 +368,38 @@ __global__ __launch_bounds__(kUfThreads, 2) void gemm_packed_kernel(
         *reinterpret_cast<uint2*>(c + (int64_t)row * n + ncol) = v;
       }
     }
+  }
+}
+
+// finish of a K-split gate_up GEMM: act = silu_and_mul(T(sum of slabs)) — one thread = 8 act columns of one row (16 B);
+// IMAGE: written as the operand image of the next GEMM (rows >= m of the last 16-row tile zero, as pack_a_kernel
+// leaves them), else row-major [m][half]
+template <typename T, bool IMAGE>
+__global__ __launch_bounds__(256) void w4a16_sum_slabs_silu_kernel(T* __restrict__ out, const float* __restrict__ slabs,
+                                                                   int m, int n, int sk) {
+  const int half = n >> 1, c8 = half >> 3;
+  const int rows = IMAGE ? (m + 15) / 16 * 16 : m;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)rows * c8) return;
+  const int row = (int)(idx / c8), c = (int)(idx - (int64_t)row * c8) * 8;
+  T o[8];
+  if (row < m) {
+    float g[8], u[8];
+    sum_slabs<8>(slabs + (int64_t)row * n + c, sk, (int64_t)m * n, g);
+    sum_slabs<8>(slabs + (int64_t)row * n + half + c, sk, (int64_t)m * n, u);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = mul_t<T>(silu_t<T>(from_f32<T>(g[e])), from_f32<T>(u[e]));
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = from_f32<T>(0.f);
+  }
+  if constexpr (IMAGE) {
+    // piece (row / 16, c / 32), slot frag_swz((c % 32) / 8, row % 16)
+    uint4* dst = reinterpret_cast<uint4*>(out) + ((int64_t)(row >> 4) * (half >> 5) + (c >> 5)) * 64 +
+                 frag_swz((c & 31) >> 3, row & 15);
+    *dst = *reinterpret_cast<const uint4*>(o);
+  } else {
+    *reinterpret_cast<uint4*>(out + (int64_t)row * half + c) = *reinterpret_cast<const uint4*>(o);
   }
 }
 
@@ -431,15 +486,15 @@ static int run_unfused(const GemmArgs& g) {
     }
     attr_once.mark(dev);
   }
-  // K split (plain epilogue only) where the tiles leave most of the chip idle: slabs behind the operand images
+  // K split where the tiles leave most of the chip idle: slabs behind the operand images
   int sk = 1;
   float* slabs = nullptr;
-  if constexpr (MODE == 0) {
+  {
     static const int forced = [] { const char* e = getenv("MI355X_W4_PACKED_SK"); return e ? atoi(e) : 0; }();
     const int64_t img_bytes = ((g.b_image ? 0 : (int64_t)g.n * g.k * 2) +
                                (g.a_packed ? 0 : (((int64_t)g.m + 15) / 16 * 16) * g.k * 2) + 15) / 16 * 16;
     if (g.dq_ws != nullptr && g.dq_ws_bytes > img_bytes && (reinterpret_cast<uintptr_t>(g.dq_ws) & 15) == 0 &&
-        g.n % 4 == 0 && (reinterpret_cast<uintptr_t>(g.c) & 7) == 0) {
+        g.n % 16 == 0 && (reinterpret_cast<uintptr_t>(g.c) & 15) == 0) {
       sk = plan_tile_split(g.m, g.n, g.k / 64, (g.dq_ws_bytes - img_bytes) / 4, forced);
       slabs = reinterpret_cast<float*>(static_cast<char*>(g.dq_ws) + img_bytes);
     }
@@ -449,9 +504,16 @@ static int run_unfused(const GemmArgs& g) {
                      g.m, g.n, g.k, num_m_blocks, num_tiles, slabs, sk);
   rc = check_launch("gemm_packed");
   if (rc || sk == 1) return rc;
-  const int64_t n4 = (int64_t)g.m * g.n / 4;
-  hipLaunchKernelGGL(w4a16_sum_slabs_kernel<T>, dim3((n4 + 255) / 256), dim3(256), 0, g.stream, static_cast<T*>(g.c),
-                     slabs, n4, sk);
+  if constexpr (SILU) {
+    const int64_t rows = MODE == 2 ? ((int64_t)g.m + 15) / 16 * 16 : g.m;
+    const int64_t threads = rows * (g.n / 16);
+    hipLaunchKernelGGL((w4a16_sum_slabs_silu_kernel<T, MODE == 2>), dim3((threads + 255) / 256), dim3(256), 0, g.stream,
+                       static_cast<T*>(g.c), slabs, g.m, g.n, sk);
+  } else {
+    const int64_t n4 = (int64_t)g.m * g.n / 4;
+    hipLaunchKernelGGL(w4a16_sum_slabs_kernel<T>, dim3((n4 + 255) / 256), dim3(256), 0, g.stream,
+                       static_cast<T*>(g.c), slabs, n4, sk);
+  }
   return check_launch("gemm_packed(sum)");
 }
 
@@ -468,7 +530,7 @@ int w4a16_gemm_unfused_dispatch(const GemmArgs& g, int dtype) {
   if (g.k % kUfBK != 0 || g.n % 64 != 0) return 1;
   // too few 256-row tiles to fill 256 CUs below 1024 rows — unless the weights' image exists already (no per-call
   // dequantisation of the whole matrix) and the plain epilogue can split K (run_unfused): then from 384 rows
-  // (Llama-3-8B layer at M = 576: stripe passes 5 x ~100 us against ... see profiles/r03_w4a16_mid_m_image.txt)
+  // (Llama-3-8B layer at M = 576: 580 us of stripe passes against 365; profiles/r03_w4a16_mid_m_image.txt)
   if (g.m < (g.b_image != nullptr ? kW4PrepackedMinM : 1024)) return 1;
   if (g.fuse_silu) {
     if (g.n % 256 != 0) return 1;   // gate and up halves must each be whole 128-column blocks
