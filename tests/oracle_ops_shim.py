@@ -10,6 +10,7 @@ import torch
 from oracle import ref_ops as R
 
 PARTITION_SIZE = 512
+W4_PREPACKED_MIN_M = 384     # (_custom_ops.W4_PREPACKED_MIN_M; the shim has no weight images: QLinear.prepack is off on CPU)
 
 
 class PackedOperand:          # the prefill-only operand image type of the real module (never produced here)
