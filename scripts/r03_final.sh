@@ -27,6 +27,9 @@ if [[ $what == *bench* ]]; then
   run rank_of_8_72b_gptq --model qwen2-72b --tp-rank-of 8 --skip-cpu || exit 2
   run bench_chunk512_awq --chunk-tokens 512 --skip-cpu --no-plugin-surface --steps 2 || exit 2
   run bench_chunk512_fp8 --quant fp8 --chunk-tokens 512 --skip-cpu --no-plugin-surface --steps 2 || exit 2
+  run bench_chunk2048_awq --chunk-tokens 2048 --skip-cpu --no-plugin-surface --steps 2 || exit 2
+  run rank_of_8_70b_fp8_chunk2048 --model llama-3-70b --tp-rank-of 8 --chunk-tokens 2048 --skip-cpu --steps 2 || exit 2
+  run rank_of_8_72b_gptq_chunk2048 --model qwen2-72b --tp-rank-of 8 --chunk-tokens 2048 --skip-cpu --steps 2 || exit 2
 fi
 if [[ $what == *prof* ]]; then
   O=gpurun_out/prof_r03f
