@@ -116,7 +116,9 @@ constexpr float kNegBig = -1.0e30f;
 // tests/kernels/attention/test_flash_attn.py:60-67), ALiBi adds slope[head] * (key - query position) to the
 // scaled score (the bias of the decode kernel, attention_kernels.cuh:286, at every query position).  A separate
 // instantiation: the plain causal path keeps its register count.
-template <typename T, bool KV8, bool IMG = false, bool OPTS = false, bool E5M2 = false>
+// QT: 16-row query tiles per wave — 2 (128 query rows per workgroup) or 1 (64: twice the workgroups for grids that
+// leave the chip half empty — chunked prefill of one or two sequences, a TP shard's few heads; same bits per row).
+template <typename T, bool KV8, bool IMG = false, bool OPTS = false, bool E5M2 = false, int QT = 2>
 __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     T* __restrict__ out, const T* __restrict__ q, const void* __restrict__ k_cache_v,
     const void* __restrict__ v_cache_v, int num_heads, int num_kv_heads, float scale,
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
   const int seq = rem - head * num_seqs_g;
   const int q_begin = cu_seqlens_q[seq];
   const int q_len = cu_seqlens_q[seq + 1] - q_begin;
-  const int m0 = qb * kPfQTile;
+  constexpr int kQTile = 64 * QT;   // query rows per workgroup
+  const int m0 = qb * kQTile;
   if (m0 >= q_len) return;
   const int seq_len = seq_lens[seq];
   const int ctx = seq_len - q_len;
@@ -161,11 +164,11 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
   const int lr = lane >> 4;
 
   // ---- Q^T B-operand fragments: qf[qt][ds] = Q[row][32*ds + 8*lr .. +7] ----------------
-  uint4 qf[2][4];
-  int qrow[2];
+  uint4 qf[QT][4];
+  int qrow[QT];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
-    qrow[qt] = m0 + wave * 32 + qt * 16 + lc;
+  for (int qt = 0; qt < QT; ++qt) {
+    qrow[qt] = m0 + wave * (16 * QT) + qt * 16 + lc;
     const int r = qrow[qt] < q_len ? qrow[qt] : q_len - 1;
     const T* qp = q + (int64_t)(q_begin + r) * q_stride + (int64_t)head * kPfD + 8 * lr;
 #pragma unroll
@@ -190,17 +193,21 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
     }
   }
 
-  f32x4_t oacc[2][8];
+  f32x4_t oacc[QT][8];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) oacc[qt][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   }
-  float mrun[2] = {kNegBig, kNegBig};
-  float lrun[2] = {0.f, 0.f};  // per-lane partial sums (its own keys only)
+  float mrun[QT], lrun[QT];    // (lrun: per-lane partial sums, its own keys only)
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrun[qt] = kNegBig;
+    lrun[qt] = 0.f;
+  }
 
   // keys needed by this workgroup: [0, kv_end)
-  const int kv_end = min(seq_len, ctx + m0 + kPfQTile);
+  const int kv_end = min(seq_len, ctx + m0 + kQTile);
   const int num_tiles = (kv_end + kPfKvTile - 1) / kPfKvTile;
   const int* block_table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
   const int num_seq_blocks = (seq_len + kPfBS - 1) / kPfBS;
@@ -267,12 +274,12 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
   if constexpr (OPTS) {
     if (alibi_slopes != nullptr) slope = alibi_slopes[head];
     if (softcap > 0.f) cap_inv2 = 2.0f * 1.4426950408889634f / softcap;   // tanh(x / cap) via 2^(2 x log2e / cap)
-    if (window > 0) wave_first = ctx + m0 + wave * 32 - window + 1;
+    if (window > 0) wave_first = ctx + m0 + wave * (16 * QT) - window + 1;
   }
   // every key <= this index is visible to EVERY query row of the wave (and is a real key)
-  const int wave_limit_lo = min(ctx + m0 + wave * 32, seq_len - 1);
+  const int wave_limit_lo = min(ctx + m0 + wave * (16 * QT), seq_len - 1);
   // the wave's first query row decides which tiles it can skip entirely (causal)
-  const int wave_q_hi = ctx + m0 + wave * 32 + 31;  // last key any row of this wave may see
+  const int wave_q_hi = ctx + m0 + wave * (16 * QT) + 16 * QT - 1;  // last key any row of this wave may see
 
   int cur = 0;   // ring slot of `tile`
   for (int tile = tile0; tile < num_tiles; ++tile) {
@@ -317,11 +324,11 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
       const uint2* vbuf = reinterpret_cast<const uint2*>(lds + cur * kStageVec + 512);
       const char* sbuf = reinterpret_cast<const char*>(lds + cur * kStageVec);   // fp8 stage image
       // ---- S^T tiles: s[b][qt] = K_b . Q_qt^T, rows = keys 16*b + 4*lr + j, col = query lc
-      f32x4_t s[2][2];
+      f32x4_t s[2][QT];
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) s[b][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int qt = 0; qt < QT; ++qt) s[b][qt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
           uint4 kf;
@@ -335,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
             kf = make_uint4(lo.x, lo.y, hi.x, hi.y);
           }
 #pragma unroll
-          for (int qt = 0; qt < 2; ++qt) s[b][qt] = MfmaQK<T>::run(kf, qf[qt][ds], s[b][qt]);
+          for (int qt = 0; qt < QT; ++qt) s[b][qt] = MfmaQK<T>::run(kf, qf[qt][ds], s[b][qt]);
         }
       }
       // ---- online softmax per query column ------------------------------------------
@@ -343,10 +350,10 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
       // fma in front of v_exp_f32 (2^x): p = 2^(s*c - m*c), c = scale*log2(e).  Masking costs VALU
       // only on tiles that reach past the wave's first visible-key limit (the diagonal / tail);
       // the accumulator rescale is skipped when no lane's running maximum moved (alpha == 1).
-      uint4 pfrag[2];
+      uint4 pfrag[QT];
       const bool need_mask = OPTS || (t0 + kPfKvTile - 1) > wave_limit_lo;
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
         float v[8];
         [[maybe_unused]] unsigned vis = 0xFFu;   // OPTS: which of the lane's 8 keys this row sees
         if constexpr (OPTS) {
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
         }
         const uint4 vf = make_uint4(v0.x, v0.y, v1.x, v1.y);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) oacc[qt][dt] = MfmaQK<T>::run(vf, pfrag[qt], oacc[qt][dt]);
+        for (int qt = 0; qt < QT; ++qt) oacc[qt][dt] = MfmaQK<T>::run(vf, pfrag[qt], oacc[qt][dt]);
       }
     }
     cur = cur + 1 == kPfStages ? 0 : cur + 1;
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_d128_kernel(
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ----------------------------------------------
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     float l = lrun[qt];
     l = rows_sum(l);
     float inv = 1.0f / l;
@@ -606,81 +613,47 @@ static int paged_prefill_impl(
   MI355X_REQUIRE(fast || alibi_slopes == nullptr, MI355X_EUNSUPPORTED,
                  "paged_prefill_attention: alibi_slopes need head_size 128, block_size 16 and a 16-bit dtype");
   if (fast) {
-    const int q_blocks = (max_query_len + kPfQTile - 1) / kPfQTile;
+    // 128 query rows per workgroup — 64 when that leaves fewer than two workgroups per CU (chunked prefill of one or
+    // two sequences, a TP shard's few heads: a workgroup is a serial chain over its key stages, and 128 workgroups take
+    // as long as 512; MI355X_PF_QT=1|2 forces a shape for A/B runs)
+    static const int forced_qt = [] { const char* e = getenv("MI355X_PF_QT"); return e ? atoi(e) : 0; }();
+    const int q_blocks128 = (max_query_len + kPfQTile - 1) / kPfQTile;
+    const bool qt1 = forced_qt ? forced_qt == 1 : (int64_t)num_seqs * q_blocks128 * num_heads < 512;
+    const int q_tile = qt1 ? 64 : kPfQTile;
+    const int q_blocks = (max_query_len + q_tile - 1) / q_tile;
     dim3 grid(num_seqs * q_blocks * num_heads), block(256);
+#define PF_KERN(...) (qt1 ? paged_prefill_d128_kernel<scalar_t, __VA_ARGS__, 1> : paged_prefill_d128_kernel<scalar_t, __VA_ARGS__, 2>)
     const size_t smem = (size_t)kPfStages * 4 * (kv8 ? 2048 : 4096);   // ring of 16- / 8-KiB stages
     return MI355X_DISPATCH_HALF(dtype, [&] {
+      // (a function pointer takes no default arguments: all 23 spelled out)
+      auto launch = [&](auto kern, bool rope, bool with_opts) {
+        hipLaunchKernelGGL(kern, grid, block, smem, s, static_cast<scalar_t*>(out),
+                           static_cast<const scalar_t*>(query), key_cache, value_cache, num_heads, num_kv_heads, scale,
+                           block_tables, seq_lens, cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride,
+                           out_stride, kv_block_stride, kv_head_stride, k_scale, v_scale,
+                           rope ? positions : nullptr,
+                           rope ? static_cast<const scalar_t*>(cos_sin_cache) : nullptr,
+                           with_opts ? sliding_window : 0, with_opts ? softcap : 0.f,
+                           with_opts ? alibi_slopes : nullptr);
+      };
       if (image) {
-        if (kv8 && e5m2) {
-          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, true, false, true>), grid, block, smem, s,
-                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
-                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
-                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                             kv_block_stride, kv_head_stride, k_scale, v_scale, positions,
-                             static_cast<const scalar_t*>(cos_sin_cache));
-        } else if (kv8) {
-          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, true>), grid, block, smem, s,
-                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
-                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
-                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                             kv_block_stride, kv_head_stride, k_scale, v_scale, positions,
-                             static_cast<const scalar_t*>(cos_sin_cache));
-        } else {
-          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, false, true>), grid, block, smem, s,
-                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
-                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
-                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                             kv_block_stride, kv_head_stride, k_scale, v_scale, positions,
-                             static_cast<const scalar_t*>(cos_sin_cache));
-        }
+        if (kv8 && e5m2) launch(PF_KERN(true, true, false, true), true, false);
+        else if (kv8) launch(PF_KERN(true, true, false, false), true, false);
+        else launch(PF_KERN(false, true, false, false), true, false);
         return check_launch("paged_prefill_attention_image");
       }
       if (opts) {
-        if (kv8 && e5m2) {
-          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, false, true, true>), grid, block, smem, s,
-                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
-                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
-                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                             kv_block_stride, kv_head_stride, k_scale, v_scale, nullptr, nullptr,
-                             sliding_window, softcap, alibi_slopes);
-        } else if (kv8) {
-          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, false, true>), grid, block, smem, s,
-                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
-                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
-                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                             kv_block_stride, kv_head_stride, k_scale, v_scale, nullptr, nullptr,
-                             sliding_window, softcap, alibi_slopes);
-        } else {
-          hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, false, false, true>), grid, block, smem, s,
-                             static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
-                             value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
-                             cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                             kv_block_stride, kv_head_stride, k_scale, v_scale, nullptr, nullptr,
-                             sliding_window, softcap, alibi_slopes);
-        }
+        if (kv8 && e5m2) launch(PF_KERN(true, false, true, true), false, true);
+        else if (kv8) launch(PF_KERN(true, false, true, false), false, true);
+        else launch(PF_KERN(false, false, true, false), false, true);
         return check_launch("paged_prefill_attention(opts)");
       }
-      if (kv8 && e5m2) {
-        hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true, false, false, true>), grid, block, smem, s,
-                           static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
-                           value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
-                           cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                           kv_block_stride, kv_head_stride, k_scale, v_scale);
-      } else if (kv8) {
-        hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, true>), grid, block, smem, s,
-                           static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
-                           value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
-                           cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                           kv_block_stride, kv_head_stride, k_scale, v_scale);
-      } else {
-        hipLaunchKernelGGL((paged_prefill_d128_kernel<scalar_t, false>), grid, block, smem, s,
-                           static_cast<scalar_t*>(out), static_cast<const scalar_t*>(query), key_cache,
-                           value_cache, num_heads, num_kv_heads, scale, block_tables, seq_lens,
-                           cu_seqlens_q, max_num_blocks_per_seq, q_blocks, q_stride, out_stride,
-                           kv_block_stride, kv_head_stride, k_scale, v_scale);
-      }
+      if (kv8 && e5m2) launch(PF_KERN(true, false, false, true), false, false);
+      else if (kv8) launch(PF_KERN(true, false, false, false), false, false);
+      else launch(PF_KERN(false, false, false, false), false, false);
       return check_launch("paged_prefill_attention");
     });
+#undef PF_KERN
   }
   // generic path needs the total number of query tokens: upper bound num_seqs * max_query_len
   const int64_t max_tokens = (int64_t)num_seqs * max_query_len;
