@@ -220,3 +220,25 @@ def test_prefill_attention_image_is_bit_identical(dtype, lens, ctx):
     img_b = ops.paged_prefill_attention_image(q, kc, vc, KVH, D ** -0.5, bt, sl, cu, max(lens), BS,
                                               positions=pos, cos_sin_cache=cos_sin)
     assert torch.equal(img_a.data.view(torch.int16), img_b.data.view(torch.int16))
+
+
+@pytest.mark.parametrize("kind", ["plain", "opts"])
+def test_prefill_query_tile_shapes_agree(kind, tmp_path):
+    """The MFMA prefill kernel with 128 and with 64 query rows per workgroup (the launcher picks 64 for grids below two
+    workgroups per CU; MI355X_PF_QT forces one, read once per process): every row's arithmetic is the same — the two
+    shapes must give the same bits.  Ragged query lengths, context > 0, window + soft cap in the `opts` case."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for qt in ("1", "2"):
+        path = str(tmp_path / f"qt{qt}.npy")
+        env = dict(os.environ, MI355X_PF_QT=qt)
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "prefill_qt_child.py"), path, kind],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
+    assert not (outs[0] == 0x7FC0).any(), "every output row must have been written (bf16 NaN fill left)"
