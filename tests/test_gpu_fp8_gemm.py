@@ -307,6 +307,29 @@ def test_scaled_mm_prefill_kernel_split_k(kind, m, n, k, bias):
         assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("m,n,k", [(700, 1024, 1152), (1030, 272, 384)])
+def test_scaled_mm_fp8_operand_sources_agree(m, n, k, tmp_path):
+    """The m > 320 fp8 kernel with its operands read in place (MI355X_F8_ROWMAJOR=3, the default), with the activations
+    in place and the weights re-tiled (1) and with both re-tiled into operand images (0): the same MFMAs on the same
+    bytes in the same k order — the same bits.  K split off (MI355X_F8_PACKED_SK=1) so that all three run one plan.
+    The switches are read once per process: three child processes."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for bits in ("3", "1", "0"):
+        path = str(tmp_path / f"rm{bits}.npy")
+        env = dict(os.environ, MI355X_F8_ROWMAJOR=bits, MI355X_F8_PACKED_SK="1")
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "helpers", "scaled_mm_child.py"), path,
+                            str(m), str(n), str(k)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert not (outs[0] == 0x7FC0).any()
+
+
 def test_scaled_mm_prepack_not_applicable():
     d = dev()
     b = torch.zeros(1000, 128, dtype=torch.int8, device=d).t()      # n = 1000: not a multiple of 64
