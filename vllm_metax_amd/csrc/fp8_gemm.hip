@@ -548,19 +548,25 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
   constexpr int kPiece = 2 * 16 * 64;     // uint4 per 64-k slice: 16 A pieces + 16 B pieces = 32 KiB
   constexpr int kStage = P * kPiece;
   constexpr int kBOff = 16 * 64;
-  // sk > 1 (few tiles: chunked-prefill sized M, narrow N): workgroup (tile, split) runs one K range and leaves its
+  // sk > 1 (few tiles: chunked-prefill sized M, narrow N): work item (tile, split) runs one K range and leaves its
   // 4-byte partial tile in slabs[split][m][n]; the finish kernel of the decode path adds the slabs in split order
-  // and applies scales / bias (deterministic, no atomics).  grid = num_tiles * sk, split-major.
-  const int split = blockIdx.x / num_tiles;
-  int tile;
-  {
-    const int b = blockIdx.x - split * num_tiles;
-    const int q = num_tiles / 8, r = num_tiles % 8;
-    const int xcd = b % 8;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-  }
-  int mb, nb;
-  {
+  // and applies scales / bias (deterministic, no atomics).  Work items = num_tiles * sk, split-major.
+  // P = 2: PERSISTENT workgroups — the grid is min(work items, one workgroup per CU), workgroup w runs items w,
+  // w + gridDim.x, ... (gridDim.x % 8 == 0 there, so an item's XCD is the one the one-item-per-workgroup launch gives
+  // it) and issues the FIRST stage of its next item in the last k iteration of the current one: the copies travel
+  // while the epilogue stores, instead of a workgroup launch and a cold first stage per tile.  Worth 1.5 % of the GEMM
+  // time (profiles/r03_fp8_prefill_persistent.txt): of the ~12 us a tile costs beyond its 1.5 us per 128-k stage most
+  // is the epilogue itself, which the only resident workgroup of a CU cannot overlap with MFMAs.
+  const int total_work = num_tiles * sk;
+  auto decode = [&](int work, int& split, int& mb, int& nb) {
+    split = work / num_tiles;
+    int tile;
+    {
+      const int b = work - split * num_tiles;
+      const int q = num_tiles / 8, r = num_tiles % 8;
+      const int xcd = b % 8;
+      tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
     constexpr int GM = 8;
     const int num_n_blocks = num_tiles / num_m_blocks;
     const int group = tile / (GM * num_n_blocks);
@@ -569,7 +575,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
     const int within = tile - group * GM * num_n_blocks;
     mb = first_m + within % gsz;
     nb = within / gsz;
-  }
+  };
+  int split, mb, nb;
+  decode(blockIdx.x, split, mb, nb);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -577,8 +585,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
   const int kpieces = k / 64;       // pieces along K
   const int kstages_all = kpieces / P;
   const int per_split = (kstages_all + sk - 1) / sk;
-  const int ks0 = split * per_split;                              // first stage of this workgroup's K range
-  const int kstages = max(0, min(per_split, kstages_all - ks0));
+  int ks0 = split * per_split;                                    // first stage of this work item's K range
+  int kstages = max(0, min(per_split, kstages_all - ks0));
 
   static_assert(P == 2 || !(AROW || BROW), "operands in place: the two-slice stage only");
   // [i][j]: row tile i of this wave; j = k slice of the stage (image) or row half 0-7 / 8-15 (row-major)
@@ -586,6 +594,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
   const uint4* b_src[2][P];
   // row-major operands: lane -> (row of the half tile, 16-byte chunk of the stage's 128 k bytes)
   const int rm_row = lane >> 3, rm_chunk = (lane & 7) ^ ((lane >> 3) & 6);
+  auto setup = [&](int mb, int nb, const uint4* (&as)[2][P], const uint4* (&bs)[2][P]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int p = wave * 2 + i;
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
       for (int j = 0; j < P; ++j) {
         int row = mb * 256 + p * 16 + 8 * j + rm_row;
         row = row < m ? row : m - 1;          // rows >= m only feed accumulator rows that are never stored
-        a_src[i][j] =
+        as[i][j] =
             reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(pa) + (int64_t)row * lda) + rm_chunk;
       }
     } else {
@@ -602,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
       const int max_mt = ((m + 15) >> 4) - 1;
       gmt = gmt < max_mt ? gmt : max_mt;
 #pragma unroll
-      for (int j = 0; j < P; ++j) a_src[i][j] = pa + ((int64_t)gmt * kpieces + j) * 64 + lane;
+      for (int j = 0; j < P; ++j) as[i][j] = pa + ((int64_t)gmt * kpieces + j) * 64 + lane;
     }
     if constexpr (BROW) {
 #pragma unroll
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
         const int r = 8 * j + rm_row;
         int col = nb * 256 + (IL ? 64 * (p >> 2) + 4 * r + (p & 3) : p * 16 + r);
         col = col < n ? col : n - 1;
-        b_src[i][j] =
+        bs[i][j] =
             reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(pb) + (int64_t)col * ldb) + rm_chunk;
       }
     } else {
@@ -619,11 +628,13 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
       const int max_nt = ((n + 15) >> 4) - 1;
       gnt = gnt < max_nt ? gnt : max_nt;
 #pragma unroll
-      for (int j = 0; j < P; ++j) b_src[i][j] = pb + ((int64_t)gnt * kpieces + j) * 64 + lane;
+      for (int j = 0; j < P; ++j) bs[i][j] = pb + ((int64_t)gnt * kpieces + j) * 64 + lane;
     }
   }
+  };
+  setup(mb, nb, a_src, b_src);
   const uint32_t lds_base = __builtin_amdgcn_readfirstlane(lds_addr_of(lds));
-  auto stage = [&](int buf, int ks) {
+  auto stage_from = [&](int buf, int ks_abs, const uint4* (&as)[2][P], const uint4* (&bs)[2][P]) {
 #pragma unroll
     for (int pp = 0; pp < P; ++pp) {
 #pragma unroll
@@ -631,20 +642,23 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
         const int p = wave * 2 + i;
         // a stage advances an image by P pieces of 64 slots, a row by P x 64 bytes = 4 P uint4
         const int dst = buf * kStage + pp * kPiece + p * 64;
-        lds_dma16(a_src[i][pp] + (int64_t)(ks0 + ks) * (AROW ? 4 * P : 64 * P), lds_base + dst * 16);
-        lds_dma16(b_src[i][pp] + (int64_t)(ks0 + ks) * (BROW ? 4 * P : 64 * P), lds_base + (dst + kBOff) * 16);
+        lds_dma16(as[i][pp] + (int64_t)ks_abs * (AROW ? 4 * P : 64 * P), lds_base + dst * 16);
+        lds_dma16(bs[i][pp] + (int64_t)ks_abs * (BROW ? 4 * P : 64 * P), lds_base + (dst + kBOff) * 16);
       }
     }
   };
+  auto stage = [&](int buf, int ks) { stage_from(buf, ks0 + ks, a_src, b_src); };
   typename Op::acc_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[i][t] = typename Op::acc_t{0, 0, 0, 0};
   }
+  if constexpr (P == 1) {
 #pragma unroll
-  for (int s2 = 0; s2 < S - 1; ++s2) {
-    if (s2 < kstages) stage(s2, s2);
+    for (int s2 = 0; s2 < S - 1; ++s2) {
+      if (s2 < kstages) stage(s2, s2);
+    }
   }
   const int frag = frag_swz(lr, lc);
   // P = 2: where a lane finds its 16 bytes of k slice 0 / 1 inside the tile's two KiB
@@ -652,92 +666,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
   const int frag_a0 = AROW ? rm2 : frag, frag_a1 = AROW ? (rm2 ^ 4) : kPiece + frag;
   const int frag_b0 = BROW ? rm2 : frag, frag_b1 = BROW ? (rm2 ^ 4) : kPiece + frag;
   int cur = 0;
-  if constexpr (P == 1) {
-    // ping-pong of the two waves of a SIMD, as in gemm_packed_kernel (w4a16_unfused.hip): waves 4-7 enter
-    // the loop one barrier late; an iteration is {12 fragment reads of stage ks, copies of stage ks+S-1,
-    // own copies of stage ks+1 retired} barrier {32 MFMAs} barrier.
-    if (kstages >= S - 1) lds_dma_wait<4 * (S - 2)>();
-    else lds_dma_wait<0>();
-    __syncthreads();
-    if (wave >= 4) __builtin_amdgcn_s_barrier();
-    for (int ks = 0; ks < kstages; ++ks) {
-      const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
-      const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
-      uint4 bf[4], af[8];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) bf[t] = bbuf[t * 64];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
-      __builtin_amdgcn_sched_barrier(0);
-      const int nxt = ks + S - 1;
-      int slot = cur + S - 1;
-      slot = slot >= S ? slot - S : slot;
-      if (nxt < kstages) {
-        stage(slot, nxt);
-        lds_dma_wait<4 * (S - 2)>();
-      } else {
-        lds_dma_wait<0>();
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[i][t] = Op::run16(af[i], bf[t], acc[i][t]);
-      }
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      cur = cur + 1 == S ? 0 : cur + 1;
-    }
-    if (wave < 4) __builtin_amdgcn_s_barrier();
-  } else {
-    // two 64-KiB stages, all 8 waves in phase, one barrier per stage.  (The ping-pong needs a copy's
-    // issue -> retire window to span a barrier epoch pair; with only two slots both groups' copies of stage
-    // ks+1 would have to go out and retire within epochs 2ks .. 2ks+1 — built and measured 4 % SLOWER than
-    // this loop, 1803 vs 1727 us per Llama-3-8B layer at M = 8192.)
-    for (int ks = 0; ks < kstages; ++ks) {
-      if (ks + S - 2 < kstages) lds_dma_wait<4 * P * (S - 2)>();
-      else lds_dma_wait<0>();
-      __syncthreads();
-      {
-        const int nxt = ks + S - 1;
-        int slot = cur + S - 1;
-        slot = slot >= S ? slot - S : slot;
-        if (nxt < kstages) stage(slot, nxt);
-      }
-      const uint4* abuf = lds + cur * kStage + (wm * 8) * 64;
-      const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64;
-      uint4 bf[4][2];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        bf[t][0] = bbuf[t * 64 + frag_b0];
-        bf[t][1] = bbuf[t * 64 + frag_b1];
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        uint4 af[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          af[i][0] = abuf[(4 * h + i) * 64 + frag_a0];
-          af[i][1] = abuf[(4 * h + i) * 64 + frag_a1];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            acc[4 * h + i][t] =
-                Op::run32(af[i][0], af[i][1], bf[t][0], bf[t][1], acc[4 * h + i][t]);
-          }
-        }
-      }
-      cur = cur + 1 == S ? 0 : cur + 1;
-    }
-  }
+  auto epilogue = [&]() {
   if (sk > 1) {
     // partial tile -> slab of this split (raw accumulators; rows / columns as in the final epilogues below)
     typename Op::elem_t* sl = slabs + (int64_t)split * m * n;
@@ -806,6 +735,128 @@ __global__ __launch_bounds__(512, 2) void gemm8_packed_kernel(
           const float as = a_scales[a_per_row ? row : 0];
           out[(int64_t)row * ldc + col] = out_cast<T>(Op::finish(acc[i][t][j], as, bs, bi));
         }
+      }
+    }
+  }
+  };
+  if constexpr (P == 1) {
+    // ping-pong of the two waves of a SIMD, as in gemm_packed_kernel (w4a16_unfused.hip): waves 4-7 enter
+    // the loop one barrier late; an iteration is {12 fragment reads of stage ks, copies of stage ks+S-1,
+    // own copies of stage ks+1 retired} barrier {32 MFMAs} barrier.
+    if (kstages >= S - 1) lds_dma_wait<4 * (S - 2)>();
+    else lds_dma_wait<0>();
+    __syncthreads();
+    if (wave >= 4) __builtin_amdgcn_s_barrier();
+    for (int ks = 0; ks < kstages; ++ks) {
+      const uint4* abuf = lds + cur * kStage + (wm * 8) * 64 + frag;
+      const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64 + frag;
+      uint4 bf[4], af[8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bf[t] = bbuf[t * 64];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) af[i] = abuf[i * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      const int nxt = ks + S - 1;
+      int slot = cur + S - 1;
+      slot = slot >= S ? slot - S : slot;
+      if (nxt < kstages) {
+        stage(slot, nxt);
+        lds_dma_wait<4 * (S - 2)>();
+      } else {
+        lds_dma_wait<0>();
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = Op::run16(af[i], bf[t], acc[i][t]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur + 1 == S ? 0 : cur + 1;
+    }
+    if (wave < 4) __builtin_amdgcn_s_barrier();
+    epilogue();
+  } else {
+    // two 64-KiB stages, all 8 waves in phase, one barrier per stage.  (The ping-pong needs a copy's
+    // issue -> retire window to span a barrier epoch pair; with only two slots both groups' copies of stage
+    // ks+1 would have to go out and retire within epochs 2ks .. 2ks+1 — built and measured 4 % SLOWER than
+    // this loop, 1803 vs 1727 us per Llama-3-8B layer at M = 8192.)
+    int work = blockIdx.x;
+    bool prefetched = false;      // the first stage of the current item is already on its way into slot `cur`
+    bool first = true;            // (a_src / b_src were set up for it above)
+    for (;;) {
+      // the next item of this workgroup, if any (scalars only: its pointers replace a_src / b_src in the last k
+      // iteration, when the current item has no stage left to issue)
+      const int nwork = work + (int)gridDim.x;
+      const bool has_next = nwork < total_work;
+      int nsplit = 0, nmb = 0, nnb = 0, nks0 = 0, nkstages = 0;
+      if (has_next) {
+        decode(nwork, nsplit, nmb, nnb);
+        nks0 = nsplit * per_split;
+        nkstages = max(0, min(per_split, kstages_all - nks0));
+      }
+      if (!prefetched) {
+        // (slot `cur` is free: its last readers passed the barrier of the previous item's last iteration)
+        if (!first) setup(mb, nb, a_src, b_src);
+        if (kstages > 0) stage(cur, 0);
+      }
+      prefetched = false;
+      first = false;
+      for (int ks = 0; ks < kstages; ++ks) {
+        lds_dma_wait<0>();
+        __syncthreads();
+        {
+          const int slot = cur ^ 1;
+          if (ks + 1 < kstages) {
+            stage(slot, ks + 1);
+          } else if (nkstages > 0) {
+            setup(nmb, nnb, a_src, b_src);
+            stage_from(slot, nks0, a_src, b_src);
+            prefetched = true;
+          }
+        }
+        const uint4* abuf = lds + cur * kStage + (wm * 8) * 64;
+        const uint4* bbuf = lds + cur * kStage + kBOff + (wn * 4) * 64;
+        uint4 bf[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          bf[t][0] = bbuf[t * 64 + frag_b0];
+          bf[t][1] = bbuf[t * 64 + frag_b1];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          uint4 af[4][2];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            af[i][0] = abuf[(4 * h + i) * 64 + frag_a0];
+            af[i][1] = abuf[(4 * h + i) * 64 + frag_a1];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              acc[4 * h + i][t] =
+                  Op::run32(af[i][0], af[i][1], bf[t][0], bf[t][1], acc[4 * h + i][t]);
+            }
+          }
+        }
+        cur ^= 1;
+      }
+      epilogue();
+      if (!has_next) break;
+      work = nwork;
+      split = nsplit; mb = nmb; nb = nnb; ks0 = nks0; kstages = nkstages;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[i][t] = typename Op::acc_t{0, 0, 0, 0};
       }
     }
   }
@@ -1032,6 +1083,17 @@ static int run_fp8(const Fp8Args& g) {
       const int num_m_blocks = (g.m + 255) / 256, num_n_blocks = (g.n + 255) / 256;
       const int num_tiles = num_m_blocks * num_n_blocks;
       const size_t smem = (size_t)4 * 2048 * sizeof(uint4);   // 128 KiB in either ring shape
+      // the two-slice kernel runs persistent workgroups, one per CU (128 KiB of LDS each: a CU holds one), over the
+      // (tile, split) items; MI355X_F8_PERSIST=0: one workgroup per item, for A/B runs
+      static const int persistent_wgs = [] {
+        const char* e = getenv("MI355X_F8_PERSIST");
+        if (e && e[0] == '0') return 1 << 30;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+          cus = 256;
+        return cus >= 8 ? cus / 8 * 8 : 8;     // (a multiple of 8: an item keeps the XCD of its index)
+      }();
       auto launch = [&](auto kern, PerDeviceOnce& once) -> int {
         int dev;
         if (once.need(&dev)) {
@@ -1044,7 +1106,8 @@ static int run_fp8(const Fp8Args& g) {
           }
           once.mark(dev);
         }
-        hipLaunchKernelGGL(kern, dim3(num_tiles * sk), dim3(512), smem, g.stream, out,
+        hipLaunchKernelGGL(kern, dim3(wide ? min(num_tiles * sk, persistent_wgs) : num_tiles * sk), dim3(512), smem,
+                           g.stream, out,
                            reinterpret_cast<const uint4*>(pa), reinterpret_cast<const uint4*>(pb),
                            g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.k, g.ldc,
                            num_m_blocks, num_tiles, g.lda, g.ldb, slabs, sk);
