@@ -1106,7 +1106,10 @@ static int run_fp8(const Fp8Args& g) {
           }
           once.mark(dev);
         }
-        hipLaunchKernelGGL(kern, dim3(wide ? min(num_tiles * sk, persistent_wgs) : num_tiles * sk), dim3(512), smem,
+        // (persistent from two rounds of items on: below that there is nothing to chain, and the chunked-prefill job
+        //  ran 3 % slower with 256 workgroups over 336 items, profiles/r03_fp8_prefill_persistent.txt)
+        const int items = num_tiles * sk;
+        hipLaunchKernelGGL(kern, dim3(wide && items >= 2 * persistent_wgs ? persistent_wgs : items), dim3(512), smem,
                            g.stream, out,
                            reinterpret_cast<const uint4*>(pa), reinterpret_cast<const uint4*>(pb),
                            g.a_scales, a_per_row, g.b_scales, b_per_col, bias, g.m, g.n, g.k, g.ldc,
