@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MI355X_ABI_VERSION 5   /* 5: + paged_attention_v2_ps, scaled_mm_fp8_deferred and its slab consumers, scaled_mm_prepack(ed) (additive); 4: + paged_prefill_attention_alibi, silu_and_mul_per_token_quant (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
+#define MI355X_ABI_VERSION 5   /* 5: + paged_attention_v2_ps, scaled_mm_fp8_deferred and its slab consumers, scaled_mm_prepack(ed), scaled_mm_split_elems, w4a16_prepacked_split_elems (additive; w4a16_gemm_prepacked takes m >= 384); 4: + paged_prefill_attention_alibi, silu_and_mul_per_token_quant (additive); 3: + greedy_advance, paged_attention_fused_qkv, *_rms_norm_image, paged_prefill_attention_image (additive);
                                 * 2 was BREAKING (kv_cache_dtype / k_scale / v_scale inserted before `stream` in reshape_and_cache*,
                                 * paged_attention_v1/_v2, paged_prefill_attention): a binding must refuse a library whose
                                 * mi355x_abi_version() differs from the version it was written for (vllm_metax_amd/_abi.py does) */
