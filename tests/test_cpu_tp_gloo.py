@@ -178,6 +178,19 @@ def test_dp_replica_aggregation_world2():
 # gloo, every rank builds ITS shard of the same model (QLinear cuts it out of the full layer), runs
 # a prefill chunk and decode steps with the real all-reduce / all-gather placement, and the greedy
 # tokens must equal those of the unsharded model.
+@pytest.fixture(autouse=True)
+def _restore_op_surface():
+    """_install_shim() swaps the op surface of harness / attention.backend IN THIS PROCESS (the tp = 1 comparison
+    run): put the real modules back after every test, so that a test that runs later in the same process sees them
+    whatever the collection order is."""
+    from vllm_metax_amd import harness
+    from vllm_metax_amd.attention import backend
+    saved = (harness.ops, backend.ops)
+    yield
+    harness.ops, backend.ops = saved
+    backend.v1_max_seq_len.cache_clear()
+
+
 def _install_shim():
     from tests import oracle_ops_shim as shim
     from vllm_metax_amd import harness

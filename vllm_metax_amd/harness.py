@@ -418,7 +418,7 @@ class HotPathModel:
         if len(pending) == 2:
             pending = (pending[0], pending[1], None)
         fuse = defer and self.cfg.tp == 1   # with tp > 1 the all-reduce sits between GEMM and norm
-        use_img = (not defer) and self.norm_image and x.shape[0] >= 1024 and pending[1] == 0 \
+        use_img = (not defer) and self.norm_image and x.shape[0] >= ops.W4_PREPACKED_MIN_M and pending[1] == 0 \
             and L.qkv.image() is not None and L.gate_up.image() is not None
         nq = cfg.quant == "fp8" and self.fuse_norm_quant and x.dtype != torch.float32 \
             and (pending[1] == 0 or pending[2] is not None)
@@ -554,14 +554,14 @@ class HotPathModel:
         residual = None
 
         # q rotary inside the attention kernel (with the image output): decided once per chunk
-        self._pf_rope_q_in_attn = bool(self.norm_image and n * q_len >= 1024 and self.cfg.head_dim == 128
+        self._pf_rope_q_in_attn = bool(self.norm_image and n * q_len >= ops.W4_PREPACKED_MIN_M and self.cfg.head_dim == 128
                                        and self.BLOCK == 16 and self.dtype != torch.float32
                                        and not self.fuse_prefill_rope
                                        and all(L.o.image() is not None for L in self.layers[:1]))
 
         def attn_fn(i, q3):
             rope = self._pf_rope_q_in_attn
-            if self.norm_image and q3.shape[0] >= 1024 and self.layers[i].o.image() is not None:
+            if self.norm_image and q3.shape[0] >= ops.W4_PREPACKED_MIN_M and self.layers[i].o.image() is not None:
                 # the attention output goes straight into o_proj's activation operand image
                 img = ops.paged_prefill_attention_image(q3, self.k_cache[i], self.v_cache[i],
                                                         self.layers[i].kv_heads, self.scale, bt, seq_lens, cu,
