@@ -518,9 +518,9 @@ __global__ __launch_bounds__(256) void gemm8_decode_kernel(
   }
 }
 
-// ------------------------------------------------------------------------- prefill (M >= 1024)
-// Same structure as the w4a16 prefill GEMM (w4a16_unfused.hip): both operands are first re-tiled
-// into 1-KiB operand images (pack_a_kernel on the byte matrices viewed as 2-byte elements: a
+// ------------------------------------------------------------------------- prefill (M > 320)
+// Same structure as the w4a16 prefill GEMM (w4a16_unfused.hip).  int8, and fp8 with K % 128 != 0: both operands are
+// first re-tiled into 1-KiB operand images (pack_a_kernel on the byte matrices viewed as 2-byte elements: a
 // piece = 16 rows x 64 k-bytes, slot frag_swz(lr, lc) = row lc, bytes 16 lr .. 16 lr + 15), then a
 // 256 x 256 tile / 8-wave kernel streams pieces by LDS-DMA through a 4-stage ring; a 16-byte
 // fragment feeds two MFMAs (low / high 8 bytes — the same k permutation on both operands).
