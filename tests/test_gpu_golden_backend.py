@@ -236,6 +236,36 @@ def test_backend_folds_the_decode_cache_write_into_the_attention_launch(spec, he
 
 
 # ----------------------------------------------------------------------------- (3) bindings
+def test_torch_ops_bindings_size_the_prefill_workspaces():
+    """torch.ops._C.cutlass_scaled_mm / awq_gemm at prefill sizes: the bindings size the scratch themselves — none for
+    fp8 operands read in place, mi355x_*_split_elems floats for the K split of shapes with few tiles — and must give
+    the bits of the ctypes path (which the parity tests cover)."""
+    import vllm_metax_amd._C  # noqa: F401
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    for m, n, k in ((576, 4096, 4096), (2048, 1280, 8192), (8192, 512, 1024)):      # split / split / in place only
+        a = (torch.randn(m, k, generator=g) * 2).clamp(-448, 448).to(torch.float8_e4m3fn).to(d)
+        b = (torch.randn(n, k, generator=g) * 2).clamp(-448, 448).to(torch.float8_e4m3fn).to(d).t()
+        a_s = (torch.rand(m, 1, generator=g) * 9e-3 + 1e-3).to(d)
+        b_s = (torch.rand(1, n, generator=g) * 9e-3 + 1e-3).to(d)
+        o1 = torch.empty(m, n, dtype=torch.bfloat16, device=d)
+        o2 = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device=d)
+        ops().cutlass_scaled_mm(o1, a, b, a_s, b_s, None)
+        torch.ops._C.cutlass_scaled_mm(o2, a, b, a_s, b_s, None)
+        assert_bit_exact(o1, o2, f"cutlass_scaled_mm binding {m}x{n}x{k}")
+    k, n = 4096, 512                                                    # 1100 x 512: 10 tiles -> K split
+    qw = torch.randint(-2**31, 2**31 - 1, (k, n // 8), generator=g, dtype=torch.int64).to(torch.int32).to(d)
+    qz = torch.randint(-2**31, 2**31 - 1, (k // 128, n // 8), generator=g, dtype=torch.int64).to(torch.int32).to(d)
+    sc = (torch.rand(k // 128, n, generator=g) * 4e-3 + 1e-3).to(torch.bfloat16).to(d)
+    q2 = ops().awq_to_gptq_4bit(qw)
+    x = (torch.randn(1100, k, generator=g) * 0.5).to(torch.bfloat16).to(d)
+    from vllm_metax_amd import _abi
+    assert _abi.load().mi355x_w4a16_prepacked_split_elems(1100, n, k) > 0
+    r1 = ops().awq_gemm(x, q2, qz, sc, 8, torch.empty(0), True)
+    r2 = torch.ops._C.awq_gemm(x, q2, sc, qz, 8, torch.empty(0, device=d), True)
+    assert_bit_exact(r1, r2, "awq_gemm binding at a prefill size")
+
+
 def test_torch_ops_bindings_match_ctypes_path():
     import vllm_metax_amd._C  # noqa: F401
     d = dev()
